@@ -1,0 +1,182 @@
+/*
+ * wavenet_hip.h -- C ABI of the MI355X (gfx950) implementation of the Wavenet training path.
+ *
+ * This is the boundary a maintainer of the reference binds against: every entry point names
+ * the reference interface it stands in for (file:line under the reference tree).  The
+ * reference has no FFI layer; its boundary is the in-process C++ API of
+ * include/Wavenet/{Wavenet,CostFunctions,LowpassOperator,HighpassOperator,MatrixOperator}.h,
+ * which wavenet_amd/host/ re-creates on top of this header.
+ *
+ * Conventions
+ *   - every array is fp64; an example is an R x C matrix stored column-major (X(r,c) at
+ *     r + c*R, as arma::Mat<double>), examples of a batch are contiguous (X + e*R*C);
+ *     R and C are powers of two; a 1D signal of length n is R = n, C = 1
+ *     (src/GeneratorBase.cxx:25-31 squeezes {1,n} to {n,1});
+ *   - pointers named *_dev are device pointers on the context's GPU, *_host are host pointers;
+ *   - all work is enqueued on the context's stream and is asynchronous unless stated;
+ *   - every function returns WN_OK or an error code and never throws; wn_last_error() gives
+ *     the message of the last failure on that context;
+ *   - a context is not re-entrant: one host thread at a time.
+ *
+ * Activations of a batch are exchanged as three arrays shaped like the input:
+ *   Prow  low-pass pyramid of every row:    Prow[r + R*(2^i + k)] = activations[0][r](i,0)(k)
+ *   Y1    coefficients after the row stage (the column stage's input)
+ *   Pcol  low-pass pyramid of every column: Pcol[(2^i + k) + R*c] = activations[1][c](i,0)(k)
+ * for levels i = 0 .. log2(len)-1; index 0 of each line is zero.  Together with X and Y they
+ * carry everything in the reference's Activations2D_t (src/Wavenet.cxx:569-580): the
+ * high-pass activations are the coefficients themselves (src/Utilities.cxx:24-41).
+ */
+#ifndef WAVENET_HIP_H
+#define WAVENET_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    WN_OK = 0,
+    WN_ERR_ARG = 1,          /* null pointer, negative count                                   */
+    WN_ERR_BAD_SHAPE = 2,    /* R or C not a power of two (src/GeneratorBase.cxx:15-49)        */
+    WN_ERR_BAD_FILTER = 3,   /* empty or odd-length filter (src/Wavenet.cxx:11-19)             */
+    WN_ERR_UNSUPPORTED = 4,  /* shape or filter length outside what this build covers          */
+    WN_ERR_HIP = 5,          /* a HIP runtime call failed                                       */
+    WN_ERR_COMM = 6,         /* an RCCL call failed                                             */
+    WN_ERR_NONFINITE = 7,    /* NaN/Inf in cost or gradient ("diverging solution",
+                                src/Wavenet.cxx:234-241)                                        */
+    WN_ERR_STATE = 8         /* call order: no filter set, no communicator, ...                 */
+};
+
+#define WN_MAX_TAPS 32       /* longest filter the compiled kernels take */
+#define WN_MAX_FUSED 4096    /* largest R*C handled by the LDS-resident kernels */
+
+typedef struct wn_context wn_context;
+
+/* ---- context ---------------------------------------------------------------------------- */
+int wn_create(int device, wn_context** ctx);
+int wn_destroy(wn_context* ctx);
+/* Use an existing hipStream_t (e.g. the caller framework's current stream); NULL = own stream. */
+int wn_set_stream(wn_context* ctx, void* hip_stream);
+int wn_synchronize(wn_context* ctx);
+const char* wn_last_error(const wn_context* ctx);
+const char* wn_status_string(int status);
+
+/* Plain device-memory helpers so that a host program needs no HIP headers. */
+int wn_malloc(wn_context* ctx, void** dev_ptr, size_t bytes);
+int wn_free(wn_context* ctx, void* dev_ptr);
+int wn_memcpy_h2d(wn_context* ctx, void* dst_dev, const void* src_host, size_t bytes); /* synchronous */
+int wn_memcpy_d2h(wn_context* ctx, void* dst_host, const void* src_dev, size_t bytes); /* synchronous */
+
+/* ---- filter operators -------------------------------------------------------------------- */
+/*
+ * Wavenet::setFilter (src/Wavenet.cxx:8-36) together with everything it invalidates:
+ * LowpassOperator(filter, i) / HighpassOperator(filter, i) for every level
+ * (Wavenet::cacheOperators_, src/Wavenet.cxx:767-786) and the weight matrices of
+ * Wavenet::cacheWeights_ (src/Wavenet.cxx:800-839).  No matrix is built: the N taps and the
+ * derived high-pass taps b_i = (-1)^i a_{N-1-i} (src/HighpassOperator.cxx:16-18) are stored on
+ * the device for the kernels.  Resets the momentum when N changes, keeps it otherwise.
+ */
+int wn_set_filter(wn_context* ctx, const double* a_host, int N);
+int wn_get_filter(wn_context* ctx, double* a_host, int* N);        /* synchronises */
+int wn_set_momentum(wn_context* ctx, const double* p_host, int N); /* Wavenet::setMomentum, Wavenet.h:174-178 */
+int wn_get_momentum(wn_context* ctx, double* p_host, int* N);      /* synchronises */
+
+/*
+ * Dense 2^size x 2^(size+1) column-major matrices, host side, for callers that still want the
+ * reference's arma::Mat view: LowpassOperator(filter,size) (include/Wavenet/LowpassOperator.h:44-45)
+ * and HighpassOperator(filter,size) (include/Wavenet/HighpassOperator.h:48-49), i.e.
+ * MatrixOperator::construct (src/MatrixOperator.cxx:5-113).  Never used by the kernels.
+ */
+int wn_lowpass_operator(const double* a_host, int N, unsigned size, double* M_host);
+int wn_highpass_operator(const double* a_host, int N, unsigned size, double* M_host);
+
+/* ---- transforms -------------------------------------------------------------------------- */
+/*
+ * Wavenet::forward_(Col) / forward_(Mat) (src/Wavenet.cxx:404-445, 562-622) followed by
+ * coeffsFromActivations (src/Utilities.cxx:24-58) on a batch.  Y_dev receives the wavelet
+ * coefficients; Prow_dev, Y1_dev, Pcol_dev receive the activations and may each be NULL.
+ */
+int wn_forward(wn_context* ctx, const double* X_dev, int B, int R, int C,
+               double* Y_dev, double* Prow_dev, double* Y1_dev, double* Pcol_dev);
+
+/* Wavenet::inverse_(Col) / inverse_(Mat) (src/Wavenet.cxx:447-472, 624-663). */
+int wn_inverse(wn_context* ctx, const double* Y_dev, int B, int R, int C, double* X_dev);
+
+/*
+ * Wavenet::backpropagate_(Col, Activations1D_t) / backpropagate_(Mat, Activations2D_t)
+ * (src/Wavenet.cxx:474-556, 665-711) with frobeniusProduct / outerProduct
+ * (include/Wavenet/Wavenet.h:870-886) on a batch.  grad_dev[e*N + k] receives the filter
+ * gradient of example e.  din_dev (may be NULL) receives the errors after the column stage,
+ * which for a 1D signal are the reference's "errors on the input" (output.at(1)).
+ */
+int wn_backprop(wn_context* ctx, const double* Delta_dev, const double* X_dev,
+                const double* Prow_dev, const double* Y1_dev, const double* Pcol_dev,
+                int B, int R, int C, double* grad_dev, double* din_dev);
+
+/* ---- cost functions ---------------------------------------------------------------------- */
+/* SparseTerm(Col/Mat) (src/CostFunctions.cxx:6-46): S_dev[e] = 1 - Gini of example e's n values. */
+int wn_sparse_term(wn_context* ctx, const double* Y_dev, int B, int n, double* S_dev);
+/* SparseTermDeriv(Col/Mat) (src/CostFunctions.cxx:49-117); S_dev may be NULL. */
+int wn_sparse_term_deriv(wn_context* ctx, const double* Y_dev, int B, int n,
+                         double* Delta_dev, double* S_dev);
+/* RegTerm / RegTermDeriv (src/CostFunctions.cxx:119-257, 259-415), host arithmetic on N taps. */
+int wn_reg_term(const double* a_host, int N, int do_wavelet, double* R_out);
+int wn_reg_term_deriv(const double* a_host, int N, int do_wavelet, double* grad_host);
+
+/* ---- training ---------------------------------------------------------------------------- */
+/*
+ * The example-dependent part of Wavenet::train (src/Wavenet.cxx:196-212 and the SparseTerm of
+ * :227) for B examples with the current filter: forward, SparseTermDeriv, backpropagate.
+ * Leaves N + 2 doubles in the context's sum buffer (see wn_sums): the sum over the batch of the
+ * sparsity gradients, the sum of SparseTerm, and the number of non-finite values met.
+ * grad_dev ([B][N]) and S_dev ([B]) receive per-example values and may be NULL.
+ */
+int wn_train_batch(wn_context* ctx, const double* X_dev, int B, int R, int C,
+                   double* grad_dev, double* S_dev);
+
+/*
+ * Device pointer to the N + 2 sums of the last wn_train_batch on this context, for the caller's
+ * all-reduce over data-parallel ranks (sum), e.g. torch.distributed / RCCL on the same stream.
+ */
+int wn_sums(wn_context* ctx, double** sums_dev, int* count);
+int wn_get_sums(wn_context* ctx, double* sums_host, int* count); /* synchronises */
+
+/*
+ * Wavenet::flushBatchQueue_ + update_ + setFilter (src/Wavenet.cxx:717-765, 8-36) on the
+ * device, from the (all-reduced) sum buffer:
+ *   gbar = (sum_g + lambda_sum * RegTermDeriv(a)) / float(batch_total)
+ *   p    = p * inertia_eff;  p += -alpha * gbar;  a = a + p
+ *   cost = (sum_S + lambda_sum * RegTerm(a_old)) / float(batch_total)
+ * lambda_sum is the sum over the batch's examples of lambda (= batch_total * lambda unless
+ * Coach's annealing changes it per event, src/Coach.cxx:176-180); inertia_eff is the caller's
+ * evaluation of src/Wavenet.cxx:757.  The new filter and the cost are appended to device-side
+ * logs (Wavenet::filterLog / costLog).
+ */
+int wn_apply_update(wn_context* ctx, double batch_total, double lambda_sum, double alpha,
+                    double inertia_eff, int do_wavelet);
+
+/* Number of updates applied since the last wn_set_filter / wn_clear_logs. */
+int wn_num_updates(wn_context* ctx, int* steps);  /* synchronises */
+/*
+ * Copies log entries [first, first+count): filters_host[count][N] are the filters after each
+ * update, costs_host[count] the batch-mean costs.  Either may be NULL.  Synchronises.
+ */
+int wn_get_logs(wn_context* ctx, int first, int count, double* filters_host, double* costs_host);
+int wn_clear_logs(wn_context* ctx);
+
+/* ---- data-parallel exchange (RCCL over xGMI) ---------------------------------------------- */
+/*
+ * One communicator per context / process.  Rank 0 calls wn_comm_unique_id and ships the 128
+ * bytes to the other ranks by any means; then every rank calls wn_comm_init.
+ * wn_allreduce_sums sums the context's N + 2 doubles over all ranks in place, on the stream.
+ */
+int wn_comm_unique_id(void* id128_host);
+int wn_comm_init(wn_context* ctx, const void* id128_host, int nranks, int rank);
+int wn_comm_destroy(wn_context* ctx);
+int wn_allreduce_sums(wn_context* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVENET_HIP_H */

@@ -1,0 +1,243 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI, on a real MI355X.
+
+Tolerance: the north star asks for <= 1e-9 relative per step on coefficients, activations,
+costs and filters; the kernels and the oracle differ only in summation order, so the bar used
+here is 1e-11 relative to the largest magnitude of each array (1e-9 for multi-step logs).
+"""
+import numpy as np
+import pytest
+
+import filters as F
+from gpu_util import dev_empty, from_dev, relerr, to_dev
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    from wavenet_amd import Context
+    assert torch.cuda.is_available()
+    c = Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    yield c
+    torch.cuda.synchronize()
+    c.close()
+
+
+def make_inputs(B, R, C, seed, sparse=False):
+    rng = np.random.default_rng(seed)
+    X = rng.random((B, R, C))
+    if sparse:
+        X = np.where(rng.random((B, R, C)) < 0.9, 0.0, X)
+        X[:, 0, 0] += 0.25  # never all-zero
+    return X
+
+
+SHAPES = [(1, 1), (2, 1), (1, 2), (2, 2), (8, 1), (1, 8), (4, 8), (16, 16), (32, 8), (128, 1), (16, 32),
+          (1024, 1), (64, 32), (64, 64), (4096, 1), (2, 1024)]
+TAPS = [2, 4, 6, 8, 16, 32]
+
+
+def filt_for(N, seed=0):
+    if N in (2, 4, 8, 16):
+        return F.perturbed(F.daubechies(N), 1e-2, seed)
+    return F.random_filter(N, seed)
+
+
+@pytest.mark.parametrize("R,C", SHAPES)
+@pytest.mark.parametrize("N", TAPS)
+def test_forward_inverse(ctx, oracle, R, C, N):
+    import torch
+    B = 3
+    a = filt_for(N, R + C)
+    X = make_inputs(B, R, C, seed=R * 7 + C + N)
+    ctx.set_filter(a)
+    n = R * C
+    dX = to_dev(X)
+    dY, dPr, dY1, dPc, dXr = (dev_empty(B * n) for _ in range(5))
+    ctx.forward(dX, B, R, C, dY, dPr, dY1, dPc)
+    ctx.inverse(dY, B, R, C, dXr)
+    torch.cuda.synchronize()
+    Y, Pr, Y1, Pc, Xr = (from_dev(t, B, R, C) for t in (dY, dPr, dY1, dPc, dXr))
+    for e in range(B):
+        oPr, oY1, oPc, oY = oracle.band_forward_2d(a, X[e])
+        assert relerr(Y[e], oY) < TOL
+        assert relerr(Y1[e], oY1) < TOL
+        assert np.abs(Pr[e] - oPr).max() < TOL * max(1.0, np.abs(oPr).max())
+        assert np.abs(Pc[e] - oPc).max() < TOL * max(1.0, np.abs(oPc).max())
+        assert relerr(Xr[e], oracle.band_inverse_2d(a, oY)) < 1e-10
+
+
+@pytest.mark.parametrize("n", [1, 2, 8, 64, 128, 256, 512, 1024, 2048, 4096])
+def test_sparse_term_and_deriv(ctx, oracle, n):
+    import torch
+    B = 4
+    rng = np.random.default_rng(n)
+    Y = rng.standard_normal((B, n))
+    Y[1, ::3] = 0.0                      # zeros: gradient 0, any rank
+    if n >= 8:
+        Y[2, :] = np.where(rng.random(n) < 0.5, 0.5, -0.5) * (1 + (np.arange(n) % 3))  # heavy non-zero ties
+        Y[3, : n // 2] = Y[3, n // 2:][::-1] * -1.0                                    # pairwise ties
+    dY = torch.from_numpy(Y.reshape(-1)).cuda()
+    dD, dS, dS2 = dev_empty(B * n), dev_empty(B), dev_empty(B)
+    ctx.sparse_term_deriv(dY, B, n, dD, dS)
+    ctx.sparse_term(dY, B, n, dS2)
+    torch.cuda.synchronize()
+    D = dD.cpu().numpy().reshape(B, n)
+    S, S2 = dS.cpu().numpy(), dS2.cpu().numpy()
+    for e in range(B):
+        oS = oracle.sparse_term(Y[e])
+        oD = oracle.sparse_term_deriv(Y[e])
+        assert S[e] == pytest.approx(oS, rel=1e-12, abs=1e-13)
+        assert S2[e] == pytest.approx(oS, rel=1e-12, abs=1e-13)
+        assert relerr(D[e], oD) < TOL, (n, e)
+        assert np.all(D[e][Y[e] == 0] == 0)
+
+
+def test_sparse_term_closed_forms(ctx):
+    import torch
+    n = 4096
+    Y = np.zeros((2, n))
+    Y[0, 1234] = -3.0
+    Y[1, :] = 0.7
+    dY = torch.from_numpy(Y.reshape(-1)).cuda()
+    dS = dev_empty(2)
+    ctx.sparse_term(dY, 2, n, dS)
+    S = dS.cpu().numpy()
+    assert S[0] == pytest.approx(1.0 / n, rel=1e-13)
+    assert S[1] == pytest.approx(1.0, abs=1e-13)
+
+
+def test_all_zero_example_is_nan_like_the_reference(ctx):
+    import torch
+    ctx.set_filter(F.DB4)
+    X = np.zeros((2, 8, 8))
+    X[1] = np.random.default_rng(0).random((8, 8))
+    ctx.train_batch(to_dev(X), 2, 8, 8)
+    s = ctx.sums()
+    assert np.isnan(s[-2]) and s[-1] > 0   # g = 0 -> 0/0 (CostFunctions.cxx:36, :102)
+
+
+@pytest.mark.parametrize("R,C", [(2, 1), (8, 1), (8, 8), (32, 8), (16, 32), (1024, 1), (64, 64), (1, 64)])
+@pytest.mark.parametrize("N", TAPS)
+def test_backprop(ctx, oracle, R, C, N):
+    import torch
+    B = 3
+    a = filt_for(N, 3)
+    rng = np.random.default_rng(R + 3 * C + N)
+    X = rng.standard_normal((B, R, C))
+    D = rng.standard_normal((B, R, C))
+    ctx.set_filter(a)
+    acts = [oracle.band_forward_2d(a, X[e]) for e in range(B)]
+    Pr = np.stack([t[0] for t in acts]); Y1 = np.stack([t[1] for t in acts]); Pc = np.stack([t[2] for t in acts])
+    dG, dDin = dev_empty(B * N), dev_empty(B * R * C)
+    ctx.backprop(to_dev(D), to_dev(X), to_dev(Pr), to_dev(Y1), to_dev(Pc), B, R, C, dG, dDin)
+    torch.cuda.synchronize()
+    G = dG.cpu().numpy().reshape(B, N)
+    Din = from_dev(dDin, B, R, C)
+    for e in range(B):
+        og = oracle.band_backprop_2d(a, D[e], X[e], Pr[e], Y1[e], Pc[e])
+        assert relerr(G[e], og) < 1e-10, (e, G[e], og)
+        if C == 1:  # 1D: errors on the input (Wavenet.cxx:553)
+            _, odin = oracle.band_backprop_1d(a, D[e][:, 0], X[e][:, 0], Pc[e][:, 0])
+            assert relerr(Din[e][:, 0], odin) < 1e-10
+
+
+@pytest.mark.parametrize("R,C,N", [(64, 64, 4), (64, 64, 16), (1024, 1, 16), (16, 16, 2), (8, 32, 6),
+                                   (64, 1, 2), (4096, 1, 32), (32, 64, 8), (4, 4, 32), (1, 1, 2)])
+def test_train_batch_sums(ctx, oracle, R, C, N):
+    import torch
+    B = 37 if R * C >= 1024 else 300
+    a = filt_for(N, 1)
+    X = make_inputs(B, R, C, seed=N, sparse=(R * C >= 256))
+    ctx.set_filter(a)
+    dG, dS = dev_empty(B * N), dev_empty(B)
+    ctx.train_batch(to_dev(X), B, R, C, dG, dS)
+    sums = ctx.sums()
+    G = dG.cpu().numpy().reshape(B, N)
+    S = dS.cpu().numpy()
+    og, os_, bad = oracle.band_train_batch(a, X)
+    assert bad == 0 and sums[N + 1] == 0
+    assert relerr(sums[:N], og) < 1e-10
+    assert sums[N] == pytest.approx(os_, rel=1e-12)
+    assert relerr(G.sum(axis=0), og) < 1e-10
+    for e in (0, B // 2, B - 1):
+        ge, se, _ = oracle.band_train_batch(a, X[e:e + 1])
+        assert relerr(G[e], ge) < 1e-10
+        assert S[e] == pytest.approx(se, rel=1e-12)
+
+
+def test_dense_reference_path_agrees(ctx, oracle):
+    """The HIP path against the DENSE restatement (matrices, outer and Frobenius products)."""
+    import torch
+    B, R, C, N = 4, 16, 8, 4
+    a = filt_for(N, 9)
+    X = make_inputs(B, R, C, seed=5)
+    ctx.set_filter(a)
+    dG, dS = dev_empty(B * N), dev_empty(B)
+    ctx.train_batch(to_dev(X), B, R, C, dG, dS)
+    torch.cuda.synchronize()
+    G = dG.cpu().numpy().reshape(B, N)
+    S = dS.cpu().numpy()
+    w = oracle.Wavenet()
+    w.set_filter(a)
+    for e in range(B):
+        AR, AC, Y = w.forward_2d(X[e])
+        g = w.backprop_2d(oracle.sparse_term_deriv(Y), AR, AC)
+        assert relerr(G[e], g) < 1e-10
+        assert S[e] == pytest.approx(oracle.sparse_term(Y), rel=1e-12)
+
+
+@pytest.mark.parametrize("R,C,N,inertia", [(16, 16, 4, 0.0), (64, 1, 2, 0.5), (8, 8, 16, 0.9)])
+def test_training_log_matches_dense_oracle(ctx, oracle, R, C, N, inertia):
+    """20 updates of batch 8: filter log and cost log against the dense Wavenet restatement
+    (Wavenet.cxx:184-242, 717-765); per-step tolerance 1e-9, drift reported by the assert."""
+    steps, Bsz, lam, alpha = 20, 8, 10.0, 1e-3
+    a0 = filt_for(N, 4)
+    X = make_inputs(steps * Bsz, R, C, seed=11)
+    w = oracle.Wavenet(lam=lam, alpha=alpha)
+    w.set_batch_size(Bsz)
+    w.set_inertia(inertia)
+    w.set_filter(a0)
+    for e in range(steps * Bsz):
+        assert w.train(X[e])
+    ofl = w.filter_log()[1:]   # entry 0 is the initial filter
+    ocl = w.cost_log()[:-1]
+
+    ctx.set_filter(a0)
+    ctx.set_momentum(np.zeros(N))
+    ctx.clear_logs()
+    dX = to_dev(X)
+    n = R * C
+    for s in range(steps):
+        ctx.train_batch(dX[s * Bsz * n:].data_ptr(), Bsz, R, C)
+        ctx.apply_update(Bsz, Bsz * lam, alpha, inertia, True)
+    fl, cl = ctx.logs()
+    assert fl.shape == ofl.shape
+    step_err = np.abs(fl - ofl).max(axis=1) / np.abs(ofl).max(axis=1)
+    assert step_err.max() < 1e-9, step_err
+    assert np.abs(cl / ocl - 1).max() < 1e-9
+    assert np.allclose(ctx.filter(), w.filter(), rtol=1e-9, atol=0)
+    assert np.allclose(ctx.momentum(), w.momentum(), rtol=1e-8, atol=1e-15)
+
+
+def test_error_codes(ctx):
+    from wavenet_amd import capi
+    d = dev_empty(64)
+    with pytest.raises(capi.WavenetError) as e:
+        ctx.forward(d, 1, 6, 1, d)
+    assert e.value.status == capi.WN_ERR_BAD_SHAPE
+    with pytest.raises(capi.WavenetError) as e:
+        ctx.set_filter(np.ones(3))
+    assert e.value.status == capi.WN_ERR_BAD_FILTER
+    with pytest.raises(capi.WavenetError) as e:
+        ctx.set_filter(np.ones(0))
+    assert e.value.status == capi.WN_ERR_BAD_FILTER
+    with pytest.raises(capi.WavenetError) as e:
+        ctx.set_filter(np.ones(34))
+    assert e.value.status == capi.WN_ERR_UNSUPPORTED
+    ctx.set_filter(F.HAAR)
+    ctx.train_batch(d, 0, 8, 8)  # empty batch: sums are zero
+    assert np.all(ctx.sums() == 0)

@@ -1,0 +1,663 @@
+// C ABI of libwavenet_hip.so (include/wavenet_hip.h): context, filter state, kernel dispatch,
+// batch reduction, on-device update, RCCL exchange.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <math.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <utility>
+
+#include "wavenet_hip.h"
+#include "wn_costfn.h"
+#include "wn_kernels.h"
+
+// kernel tables, one translation unit per compiled tap count (wn_fused_np.hip)
+extern "C" const void* wn_kernel_np2(int kind, int sc);
+extern "C" const void* wn_kernel_np4(int kind, int sc);
+extern "C" const void* wn_kernel_np8(int kind, int sc);
+extern "C" const void* wn_kernel_np16(int kind, int sc);
+extern "C" const void* wn_kernel_np32(int kind, int sc);
+extern "C" const void* wn_kernel_sparse(int sc);
+
+namespace {
+
+enum { KIND_TRAIN = 0, KIND_FORWARD = 1, KIND_INVERSE = 2, KIND_BACKPROP = 3 };
+
+struct SizeClass { int T, Q, NS; };
+const SizeClass kSizeClasses[5] = {{64, 1, 128}, {64, 3, 512}, {128, 3, 1024}, {256, 3, 2048}, {512, 3, 4096}};
+const int kLogCap = 16384;
+
+thread_local std::string g_error;  // for the entry points that take no context
+
+}  // namespace
+
+struct wn_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int numCU = 0;
+    wn::FilterDev* dfilt = nullptr;
+    bool has_filter = false;
+    int N = 0, NP = 0;
+    double* partial = nullptr;
+    int partial_blocks = 0;
+    double* sums = nullptr;
+    double* log_filters = nullptr;
+    double* log_costs = nullptr;
+    void* nccl_lib = nullptr;
+    void* comm = nullptr;
+    int nranks = 1;
+    std::string err;
+    std::map<const void*, size_t> lds_configured;
+    std::map<std::pair<const void*, size_t>, int> occupancy;
+};
+
+namespace {
+
+int fail(wn_context* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    g_error = msg;
+    return code;
+}
+
+#define WN_HIP(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ctx, WN_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+int ilog2_exact(int v) {  // -1 unless v is a power of two >= 1
+    if (v < 1 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) l++;
+    return l;
+}
+
+int size_class(long long n) {
+    if (n <= 128) return 0;
+    if (n <= 512) return 1;
+    if (n <= 1024) return 2;
+    if (n <= 2048) return 3;
+    if (n <= 4096) return 4;
+    return -1;
+}
+
+int compiled_taps(int N) {
+    for (int np : {2, 4, 8, 16, 32}) {
+        if (N <= np) return np;
+    }
+    return -1;
+}
+
+const void* fused_kernel(int NP, int kind, int sc) {
+    switch (NP) {
+        case 2: return wn_kernel_np2(kind, sc);
+        case 4: return wn_kernel_np4(kind, sc);
+        case 8: return wn_kernel_np8(kind, sc);
+        case 16: return wn_kernel_np16(kind, sc);
+        case 32: return wn_kernel_np32(kind, sc);
+    }
+    return nullptr;
+}
+
+// Checks (B, R, C) and the filter; fills lgR, lgC, sc.
+int check_shape(wn_context* ctx, int B, int R, int C, bool need_filter, int* lgR, int* lgC, int* sc) {
+    if (!ctx) return WN_ERR_ARG;
+    if (B < 0) return fail(ctx, WN_ERR_ARG, "negative batch size");
+    *lgR = ilog2_exact(R);
+    *lgC = ilog2_exact(C);
+    if (*lgR < 0 || *lgC < 0)
+        return fail(ctx, WN_ERR_BAD_SHAPE, "shape {" + std::to_string(R) + ", " + std::to_string(C) + "} is not radix 2");
+    if (need_filter && !ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
+    *sc = size_class((long long)R * C);
+    if (*sc < 0)
+        return fail(ctx, WN_ERR_UNSUPPORTED, "R*C = " + std::to_string((long long)R * C) + " exceeds " +
+                                                  std::to_string(WN_MAX_FUSED) + " (LDS-resident kernels)");
+    return WN_OK;
+}
+
+int launch(wn_context* ctx, const void* func, int T, size_t shmem, int B, wn::FusedArgs& A, int* grid_out) {
+    if (!func) return fail(ctx, WN_ERR_UNSUPPORTED, "no kernel compiled for this configuration");
+    auto it = ctx->lds_configured.find(func);
+    if (it == ctx->lds_configured.end() || it->second < shmem) {
+        WN_HIP(ctx, hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        ctx->lds_configured[func] = shmem;
+    }
+    auto key = std::make_pair(func, shmem);
+    auto oc = ctx->occupancy.find(key);
+    int perCU;
+    if (oc == ctx->occupancy.end()) {
+        int nb = 0;
+        WN_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, func, T, shmem));
+        perCU = nb < 1 ? 1 : nb;
+        ctx->occupancy[key] = perCU;
+    } else {
+        perCU = oc->second;
+    }
+    long long grid = (long long)perCU * ctx->numCU;
+    if (grid > B) grid = B;
+    if (grid < 1) grid = 1;
+    if (grid_out) *grid_out = (int)grid;
+    void* args[] = {&A};
+    WN_HIP(ctx, hipLaunchKernel(func, dim3((unsigned)grid), dim3((unsigned)T), args, shmem, ctx->stream));
+    return WN_OK;
+}
+
+// ---- small kernels ----------------------------------------------------------------------------
+
+// Sums the per-workgroup partials in workgroup order: sums[0..N) gradient, [N] sparse term,
+// [N+1] non-finite count.
+__global__ void k_reduce_partials(const double* partial, int nblocks, int N, double* sums) {
+    const int t = threadIdx.x;
+    if (t > N + 1) return;
+    double s = 0;
+    for (int blk = 0; blk < nblocks; blk++) s += partial[(size_t)blk * wn::PSTRIDE + t];
+    sums[t] = s;
+}
+
+__device__ void write_padded_filter(wn::FilterDev* f, const double* a) {
+    const int N = f->N, d = f->d;
+    for (int j = 0; j < wn::MAXTAPS; j++) { f->a[j] = 0; f->b[j] = 0; }
+    for (int j = 0; j < N; j++) {
+        f->a_true[j] = a[j];
+        f->a[j + d] = a[j];
+        f->b[j + d] = wn::parity_sign(j) * a[N - 1 - j];
+    }
+}
+
+// Wavenet::flushBatchQueue_ / update_ / setFilter (src/Wavenet.cxx:717-765, 8-36), one thread.
+__global__ void k_update(wn::FilterDev* f, const double* sums, double Bf, double lambda_sum, double alpha,
+                         double inertia_eff, int wavelet, double* logF, double* logC, int cap) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int N = f->N;
+    double a[wn::MAXTAPS], regd[wn::MAXTAPS];
+    for (int k = 0; k < N; k++) a[k] = f->a_true[k];
+    wn::reg_term_deriv(a, N, wavelet != 0, regd);
+    const double reg = wn::reg_term(a, N, wavelet != 0);
+    for (int k = 0; k < N; k++) {
+        double gbar = sums[k] + lambda_sum * regd[k];
+        gbar /= Bf;                                   // gradient /= float(size)          :727
+        double p = f->momentum[k] * inertia_eff;      // scaleMomentum_                    :760
+        p += -alpha * gbar;                           // addMomentum_                      :761
+        f->momentum[k] = p;
+        a[k] = a[k] + p;                              // setFilter(m_filter + m_momentum)  :762
+    }
+    const double cost = (sums[N] + lambda_sum * reg) / Bf;  // :227, :733
+    write_padded_filter(f, a);
+    const int idx = f->steps % cap;
+    for (int k = 0; k < wn::MAXTAPS; k++) logF[(size_t)idx * wn::MAXTAPS + k] = (k < N) ? a[k] : 0.0;
+    logC[idx] = cost;
+    f->steps = f->steps + 1;
+}
+
+__global__ void k_reset_steps(wn::FilterDev* f) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) f->steps = 0;
+}
+
+// ---- RCCL through dlopen: the library is only needed by multi-GPU callers ----------------------
+struct NcclId { char internal[128]; };
+typedef int (*fn_ncclGetUniqueId)(NcclId*);
+typedef int (*fn_ncclCommInitRank)(void**, int, NcclId, int);
+typedef int (*fn_ncclAllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_ncclCommDestroy)(void*);
+typedef const char* (*fn_ncclGetErrorString)(int);
+const int kNcclDouble = 8, kNcclSum = 0;
+
+void* open_rccl() {
+    static void* lib = nullptr;
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    return lib;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* wn_status_string(int status) {
+    switch (status) {
+        case WN_OK: return "ok";
+        case WN_ERR_ARG: return "bad argument";
+        case WN_ERR_BAD_SHAPE: return "shape is not radix 2";
+        case WN_ERR_BAD_FILTER: return "filter is empty or of odd length";
+        case WN_ERR_UNSUPPORTED: return "unsupported size";
+        case WN_ERR_HIP: return "HIP runtime error";
+        case WN_ERR_COMM: return "RCCL error";
+        case WN_ERR_NONFINITE: return "non-finite cost or gradient";
+        case WN_ERR_STATE: return "call order";
+    }
+    return "unknown status";
+}
+
+const char* wn_last_error(const wn_context* ctx) { return ctx ? ctx->err.c_str() : g_error.c_str(); }
+
+int wn_create(int device, wn_context** out) {
+    if (!out) return WN_ERR_ARG;
+    *out = nullptr;
+    wn_context* ctx = new wn_context();
+    ctx->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        g_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        delete ctx;
+        return WN_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        g_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        delete ctx;
+        return WN_ERR_HIP;
+    }
+    ctx->numCU = prop.multiProcessorCount;
+    int rc = WN_OK;
+    auto alloc = [&](void** p, size_t bytes) {
+        hipError_t ee = hipMalloc(p, bytes);
+        if (ee == hipSuccess) ee = hipMemset(*p, 0, bytes);
+        if (ee != hipSuccess) { g_error = std::string("hipMalloc: ") + hipGetErrorString(ee); rc = WN_ERR_HIP; }
+    };
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) rc = WN_ERR_HIP;
+    ctx->own_stream = true;
+    ctx->partial_blocks = ctx->numCU * 16;
+    if (rc == WN_OK) alloc((void**)&ctx->dfilt, sizeof(wn::FilterDev));
+    if (rc == WN_OK) alloc((void**)&ctx->partial, (size_t)ctx->partial_blocks * wn::PSTRIDE * sizeof(double));
+    if (rc == WN_OK) alloc((void**)&ctx->sums, wn::PSTRIDE * sizeof(double));
+    if (rc == WN_OK) alloc((void**)&ctx->log_filters, (size_t)kLogCap * wn::MAXTAPS * sizeof(double));
+    if (rc == WN_OK) alloc((void**)&ctx->log_costs, (size_t)kLogCap * sizeof(double));
+    if (rc != WN_OK) {
+        wn_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return WN_OK;
+}
+
+int wn_destroy(wn_context* ctx) {
+    if (!ctx) return WN_OK;
+    (void)hipSetDevice(ctx->device);
+    wn_comm_destroy(ctx);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->dfilt);
+    (void)hipFree(ctx->partial);
+    (void)hipFree(ctx->sums);
+    (void)hipFree(ctx->log_filters);
+    (void)hipFree(ctx->log_costs);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return WN_OK;
+}
+
+int wn_set_stream(wn_context* ctx, void* hip_stream) {
+    if (!ctx) return WN_ERR_ARG;
+    WN_HIP(ctx, hipSetDevice(ctx->device));
+    WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->own_stream = false;
+    ctx->stream = (hipStream_t)hip_stream;
+    if (!hip_stream) {
+        WN_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return WN_OK;
+}
+
+int wn_synchronize(wn_context* ctx) {
+    if (!ctx) return WN_ERR_ARG;
+    WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WN_OK;
+}
+
+int wn_malloc(wn_context* ctx, void** dev_ptr, size_t bytes) {
+    if (!ctx || !dev_ptr) return WN_ERR_ARG;
+    WN_HIP(ctx, hipSetDevice(ctx->device));
+    WN_HIP(ctx, hipMalloc(dev_ptr, bytes ? bytes : 8));
+    return WN_OK;
+}
+
+int wn_free(wn_context* ctx, void* dev_ptr) {
+    if (!ctx) return WN_ERR_ARG;
+    WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WN_HIP(ctx, hipFree(dev_ptr));
+    return WN_OK;
+}
+
+int wn_memcpy_h2d(wn_context* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    if (!ctx || (bytes && (!dst_dev || !src_host))) return WN_ERR_ARG;
+    WN_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WN_OK;
+}
+
+int wn_memcpy_d2h(wn_context* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    if (!ctx || (bytes && (!dst_host || !src_dev))) return WN_ERR_ARG;
+    WN_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WN_OK;
+}
+
+// ---- filter ---------------------------------------------------------------------------------------
+
+int wn_set_filter(wn_context* ctx, const double* a, int N) {
+    if (!ctx) return WN_ERR_ARG;
+    if (!a || N <= 0) return fail(ctx, WN_ERR_BAD_FILTER, "Input filter is empty.");
+    if (N % 2) return fail(ctx, WN_ERR_BAD_FILTER, "Input filter length is not a multiple of 2.");
+    const int NP = compiled_taps(N);
+    if (NP < 0)
+        return fail(ctx, WN_ERR_UNSUPPORTED, "filter length " + std::to_string(N) + " exceeds " + std::to_string(WN_MAX_TAPS));
+    wn::FilterDev h;
+    memset(&h, 0, sizeof(h));
+    const int d = (NP - N) / 2;
+    for (int j = 0; j < N; j++) {
+        h.a_true[j] = a[j];
+        h.a[j + d] = a[j];
+        h.b[j + d] = wn::parity_sign(j) * a[N - 1 - j];
+        h.vL[j + d] = 1.0;
+        h.sH[j + d] = wn::parity_sign(N - 1 - j);
+    }
+    h.N = N;
+    h.NP = NP;
+    h.d = d;
+    // taps and lengths; momentum and the log counter stay on the device
+    WN_HIP(ctx, hipMemcpyAsync(ctx->dfilt, &h, offsetof(wn::FilterDev, momentum), hipMemcpyHostToDevice, ctx->stream));
+    WN_HIP(ctx, hipMemcpyAsync(&ctx->dfilt->N, &h.N, 3 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    if (!ctx->has_filter || ctx->N != N) {
+        WN_HIP(ctx, hipMemsetAsync(ctx->dfilt->momentum, 0, sizeof(h.momentum), ctx->stream));  // :31-33
+    }
+    WN_HIP(ctx, hipStreamSynchronize(ctx->stream));  // h is a stack object
+    ctx->has_filter = true;
+    ctx->N = N;
+    ctx->NP = NP;
+    return WN_OK;
+}
+
+int wn_get_filter(wn_context* ctx, double* a, int* N) {
+    if (!ctx) return WN_ERR_ARG;
+    if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
+    if (N) *N = ctx->N;
+    if (a) return wn_memcpy_d2h(ctx, a, ctx->dfilt->a_true, (size_t)ctx->N * sizeof(double));
+    return WN_OK;
+}
+
+int wn_set_momentum(wn_context* ctx, const double* p, int N) {
+    if (!ctx || !p) return WN_ERR_ARG;
+    if (!ctx->has_filter || N != ctx->N) return fail(ctx, WN_ERR_STATE, "momentum length differs from the filter's");
+    return wn_memcpy_h2d(ctx, ctx->dfilt->momentum, p, (size_t)N * sizeof(double));
+}
+
+int wn_get_momentum(wn_context* ctx, double* p, int* N) {
+    if (!ctx) return WN_ERR_ARG;
+    if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
+    if (N) *N = ctx->N;
+    if (p) return wn_memcpy_d2h(ctx, p, ctx->dfilt->momentum, (size_t)ctx->N * sizeof(double));
+    return WN_OK;
+}
+
+static int dense_operator(const double* f, int N, unsigned size, double* M) {
+    if (!f || !M || N <= 0) return WN_ERR_ARG;
+    if (N % 2) return WN_ERR_BAD_FILTER;
+    if (size > 13) return WN_ERR_UNSUPPORTED;  // 2^13 x 2^14 doubles = 1 GiB
+    const size_t nRows = (size_t)1 << size, nCols = (size_t)2 << size;
+    memset(M, 0, nRows * nCols * sizeof(double));
+    for (size_t r = 0; r < nRows; r++) {
+        for (int j = 0; j < N; j++) {
+            const size_t c = (size_t)((long long)(N / 2) + 2 * (long long)r - j) & (nCols - 1);
+            M[r + c * nRows] += f[j];
+        }
+    }
+    return WN_OK;
+}
+
+int wn_lowpass_operator(const double* a, int N, unsigned size, double* M) { return dense_operator(a, N, size, M); }
+
+int wn_highpass_operator(const double* a, int N, unsigned size, double* M) {
+    if (!a || N <= 0 || N > 4096) return WN_ERR_ARG;
+    if (N % 2) return WN_ERR_BAD_FILTER;
+    double b[4096];
+    for (int i = 0; i < N; i++) b[i] = wn::parity_sign(i) * a[N - 1 - i];
+    return dense_operator(b, N, size, M);
+}
+
+// ---- transforms -----------------------------------------------------------------------------------
+
+int wn_forward(wn_context* ctx, const double* X, int B, int R, int C, double* Y, double* Prow, double* Y1, double* Pcol) {
+    int lgR, lgC, sc;
+    int rc = check_shape(ctx, B, R, C, true, &lgR, &lgC, &sc);
+    if (rc) return rc;
+    if (B == 0) return WN_OK;
+    if (!X) return fail(ctx, WN_ERR_ARG, "null input");
+    const SizeClass& S = kSizeClasses[sc];
+    wn::FusedArgs A;
+    memset(&A, 0, sizeof(A));
+    A.B = B; A.lgR = lgR; A.lgC = lgC; A.filt = ctx->dfilt;
+    A.X = X; A.Y = Y; A.Prow = Prow; A.Y1 = Y1; A.Pcol = Pcol;
+    const size_t shmem = (size_t)4 * R * C * sizeof(double);
+    return launch(ctx, fused_kernel(ctx->NP, KIND_FORWARD, sc), S.T, shmem, B, A, nullptr);
+}
+
+int wn_inverse(wn_context* ctx, const double* Y, int B, int R, int C, double* X) {
+    int lgR, lgC, sc;
+    int rc = check_shape(ctx, B, R, C, true, &lgR, &lgC, &sc);
+    if (rc) return rc;
+    if (B == 0) return WN_OK;
+    if (!Y || !X) return fail(ctx, WN_ERR_ARG, "null pointer");
+    const SizeClass& S = kSizeClasses[sc];
+    wn::FusedArgs A;
+    memset(&A, 0, sizeof(A));
+    A.B = B; A.lgR = lgR; A.lgC = lgC; A.filt = ctx->dfilt;
+    A.Yin = Y; A.Xout = X;
+    const size_t shmem = (size_t)R * C * sizeof(double) + 16;
+    return launch(ctx, fused_kernel(ctx->NP, KIND_INVERSE, sc), S.T, shmem, B, A, nullptr);
+}
+
+int wn_backprop(wn_context* ctx, const double* Delta, const double* X, const double* Prow, const double* Y1,
+                const double* Pcol, int B, int R, int C, double* grad, double* din) {
+    int lgR, lgC, sc;
+    int rc = check_shape(ctx, B, R, C, true, &lgR, &lgC, &sc);
+    if (rc) return rc;
+    if (B == 0) return WN_OK;
+    if (!Delta || !X || !Prow || !Y1 || !Pcol || !grad) return fail(ctx, WN_ERR_ARG, "null pointer");
+    const SizeClass& S = kSizeClasses[sc];
+    wn::FusedArgs A;
+    memset(&A, 0, sizeof(A));
+    A.B = B; A.lgR = lgR; A.lgC = lgC; A.filt = ctx->dfilt;
+    A.Din = Delta; A.X = X; A.ProwIn = Prow; A.Y1In = Y1; A.PcolIn = Pcol; A.grad = grad; A.Delta = din;
+    const size_t shmem = ((size_t)4 * R * C + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double);
+    return launch(ctx, fused_kernel(ctx->NP, KIND_BACKPROP, sc), S.T, shmem, B, A, nullptr);
+}
+
+// ---- cost functions -------------------------------------------------------------------------------
+
+int wn_sparse_term_deriv(wn_context* ctx, const double* Y, int B, int n, double* Delta, double* Sout) {
+    if (!ctx) return WN_ERR_ARG;
+    if (B < 0 || n < 1) return fail(ctx, WN_ERR_ARG, "bad counts");
+    // any n is accepted by the reference; the sort kernels take powers of two
+    int lgn = ilog2_exact(n);
+    if (lgn < 0) return fail(ctx, WN_ERR_BAD_SHAPE, "number of coefficients is not radix 2");
+    const int sc = size_class(n);
+    if (sc < 0) return fail(ctx, WN_ERR_UNSUPPORTED, "n exceeds the LDS-resident kernels");
+    if (B == 0) return WN_OK;
+    if (!Y) return fail(ctx, WN_ERR_ARG, "null input");
+    const SizeClass& S = kSizeClasses[sc];
+    wn::FusedArgs A;
+    memset(&A, 0, sizeof(A));
+    A.B = B; A.lgR = lgn; A.lgC = 0;
+    A.Yin = Y; A.Delta = Delta; A.S = Sout;
+    const size_t shmem = ((size_t)S.NS + S.T / 64 + 2) * sizeof(double) + 16;
+    return launch(ctx, wn_kernel_sparse(sc), S.T, shmem, B, A, nullptr);
+}
+
+int wn_sparse_term(wn_context* ctx, const double* Y, int B, int n, double* Sout) {
+    if (ctx && !Sout) return fail(ctx, WN_ERR_ARG, "null output");
+    return wn_sparse_term_deriv(ctx, Y, B, n, nullptr, Sout);
+}
+
+int wn_reg_term(const double* a, int N, int do_wavelet, double* R_out) {
+    if (!a || !R_out || N <= 0) return WN_ERR_ARG;
+    if (N % 2) return WN_ERR_BAD_FILTER;
+    if (N > 64) return WN_ERR_UNSUPPORTED;
+    *R_out = wn::reg_term(a, N, do_wavelet != 0);
+    return WN_OK;
+}
+
+int wn_reg_term_deriv(const double* a, int N, int do_wavelet, double* grad) {
+    if (!a || !grad || N <= 0) return WN_ERR_ARG;
+    if (N % 2) return WN_ERR_BAD_FILTER;
+    if (N > 64) return WN_ERR_UNSUPPORTED;
+    wn::reg_term_deriv(a, N, do_wavelet != 0, grad);
+    return WN_OK;
+}
+
+// ---- training ---------------------------------------------------------------------------------------
+
+int wn_train_batch(wn_context* ctx, const double* X, int B, int R, int C, double* grad, double* Sout) {
+    int lgR, lgC, sc;
+    int rc = check_shape(ctx, B, R, C, true, &lgR, &lgC, &sc);
+    if (rc) return rc;
+    if (B > 0 && !X) return fail(ctx, WN_ERR_ARG, "null input");
+    const SizeClass& S = kSizeClasses[sc];
+    wn::FusedArgs A;
+    memset(&A, 0, sizeof(A));
+    A.B = B; A.lgR = lgR; A.lgC = lgC; A.filt = ctx->dfilt;
+    A.X = X; A.grad = grad; A.S = Sout; A.partial = ctx->partial;
+    int grid = 0;
+    if (B > 0) {
+        const size_t shmem = ((size_t)3 * R * C + S.NS + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double) + 16;
+        rc = launch(ctx, fused_kernel(ctx->NP, KIND_TRAIN, sc), S.T, shmem, B, A, &grid);
+        if (rc) return rc;
+        if (grid > ctx->partial_blocks) return fail(ctx, WN_ERR_STATE, "partial buffer too small");
+    }
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, ctx->stream, ctx->partial, grid, ctx->N, ctx->sums);
+    WN_HIP(ctx, hipGetLastError());
+    return WN_OK;
+}
+
+int wn_sums(wn_context* ctx, double** sums_dev, int* count) {
+    if (!ctx) return WN_ERR_ARG;
+    if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
+    if (sums_dev) *sums_dev = ctx->sums;
+    if (count) *count = ctx->N + 2;
+    return WN_OK;
+}
+
+int wn_get_sums(wn_context* ctx, double* sums_host, int* count) {
+    if (!ctx) return WN_ERR_ARG;
+    if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
+    if (count) *count = ctx->N + 2;
+    if (sums_host) return wn_memcpy_d2h(ctx, sums_host, ctx->sums, (size_t)(ctx->N + 2) * sizeof(double));
+    return WN_OK;
+}
+
+int wn_apply_update(wn_context* ctx, double batch_total, double lambda_sum, double alpha, double inertia_eff,
+                    int do_wavelet) {
+    if (!ctx) return WN_ERR_ARG;
+    if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
+    if (!(batch_total >= 1)) return fail(ctx, WN_ERR_ARG, "batch_total must be >= 1");
+    const double Bf = (double)(float)batch_total;  // the reference divides by float(size)
+    hipLaunchKernelGGL(k_update, dim3(1), dim3(64), 0, ctx->stream, ctx->dfilt, ctx->sums, Bf, lambda_sum, alpha,
+                       inertia_eff, do_wavelet, ctx->log_filters, ctx->log_costs, kLogCap);
+    WN_HIP(ctx, hipGetLastError());
+    return WN_OK;
+}
+
+int wn_num_updates(wn_context* ctx, int* steps) {
+    if (!ctx || !steps) return WN_ERR_ARG;
+    return wn_memcpy_d2h(ctx, steps, &ctx->dfilt->steps, sizeof(int));
+}
+
+int wn_get_logs(wn_context* ctx, int first, int count, double* filters, double* costs) {
+    if (!ctx || first < 0 || count < 0) return WN_ERR_ARG;
+    if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
+    int steps = 0;
+    int rc = wn_num_updates(ctx, &steps);
+    if (rc) return rc;
+    if (first + count > steps || steps - first > kLogCap)
+        return fail(ctx, WN_ERR_ARG, "log range not available (" + std::to_string(steps) + " updates, ring of " +
+                                         std::to_string(kLogCap) + ")");
+    const int N = ctx->N;
+    double row[wn::MAXTAPS];
+    for (int i = 0; i < count; i++) {
+        const int idx = (first + i) % kLogCap;
+        if (filters) {
+            rc = wn_memcpy_d2h(ctx, row, ctx->log_filters + (size_t)idx * wn::MAXTAPS, sizeof(row));
+            if (rc) return rc;
+            memcpy(filters + (size_t)i * N, row, (size_t)N * sizeof(double));
+        }
+        if (costs) {
+            rc = wn_memcpy_d2h(ctx, costs + i, ctx->log_costs + idx, sizeof(double));
+            if (rc) return rc;
+        }
+    }
+    return WN_OK;
+}
+
+int wn_clear_logs(wn_context* ctx) {
+    if (!ctx) return WN_ERR_ARG;
+    hipLaunchKernelGGL(k_reset_steps, dim3(1), dim3(64), 0, ctx->stream, ctx->dfilt);
+    WN_HIP(ctx, hipGetLastError());
+    return WN_OK;
+}
+
+// ---- RCCL ---------------------------------------------------------------------------------------------
+
+int wn_comm_unique_id(void* id128) {
+    if (!id128) return WN_ERR_ARG;
+    void* lib = open_rccl();
+    if (!lib) { g_error = std::string("dlopen librccl: ") + dlerror(); return WN_ERR_COMM; }
+    auto f = (fn_ncclGetUniqueId)dlsym(lib, "ncclGetUniqueId");
+    if (!f) { g_error = "ncclGetUniqueId not found"; return WN_ERR_COMM; }
+    NcclId id;
+    const int r = f(&id);
+    if (r != 0) { g_error = "ncclGetUniqueId failed: " + std::to_string(r); return WN_ERR_COMM; }
+    memcpy(id128, &id, sizeof(id));
+    return WN_OK;
+}
+
+int wn_comm_init(wn_context* ctx, const void* id128, int nranks, int rank) {
+    if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return WN_ERR_ARG;
+    if (ctx->comm) return fail(ctx, WN_ERR_STATE, "communicator already initialised");
+    void* lib = open_rccl();
+    if (!lib) return fail(ctx, WN_ERR_COMM, std::string("dlopen librccl: ") + dlerror());
+    auto f = (fn_ncclCommInitRank)dlsym(lib, "ncclCommInitRank");
+    if (!f) return fail(ctx, WN_ERR_COMM, "ncclCommInitRank not found");
+    WN_HIP(ctx, hipSetDevice(ctx->device));
+    NcclId id;
+    memcpy(&id, id128, sizeof(id));
+    void* comm = nullptr;
+    const int r = f(&comm, nranks, id, rank);
+    if (r != 0) return fail(ctx, WN_ERR_COMM, "ncclCommInitRank failed: " + std::to_string(r));
+    ctx->nccl_lib = lib;
+    ctx->comm = comm;
+    ctx->nranks = nranks;
+    return WN_OK;
+}
+
+int wn_comm_destroy(wn_context* ctx) {
+    if (!ctx) return WN_ERR_ARG;
+    if (ctx->comm && ctx->nccl_lib) {
+        auto f = (fn_ncclCommDestroy)dlsym(ctx->nccl_lib, "ncclCommDestroy");
+        if (f) f(ctx->comm);
+    }
+    ctx->comm = nullptr;
+    ctx->nranks = 1;
+    return WN_OK;
+}
+
+int wn_allreduce_sums(wn_context* ctx) {
+    if (!ctx) return WN_ERR_ARG;
+    if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
+    if (!ctx->comm) return fail(ctx, WN_ERR_STATE, "no communicator: call wn_comm_init first");
+    auto f = (fn_ncclAllReduce)dlsym(ctx->nccl_lib, "ncclAllReduce");
+    if (!f) return fail(ctx, WN_ERR_COMM, "ncclAllReduce not found");
+    const int r = f(ctx->sums, ctx->sums, (size_t)(ctx->N + 2), kNcclDouble, kNcclSum, ctx->comm, ctx->stream);
+    if (r != 0) return fail(ctx, WN_ERR_COMM, "ncclAllReduce failed: " + std::to_string(r));
+    return WN_OK;
+}
+
+}  // extern "C"
