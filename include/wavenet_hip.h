@@ -56,7 +56,9 @@ typedef struct wn_context wn_context;
 /* ---- context ---------------------------------------------------------------------------- */
 int wn_create(int device, wn_context** ctx);
 int wn_destroy(wn_context* ctx);
-/* Use an existing hipStream_t (e.g. the caller framework's current stream); NULL = own stream. */
+/* A context starts on a stream of its own.  This switches it to the caller's hipStream_t (e.g. the
+ * framework's current stream) so that its work is ordered with the caller's; NULL is HIP's default
+ * (null) stream. */
 int wn_set_stream(wn_context* ctx, void* hip_stream);
 int wn_synchronize(wn_context* ctx);
 const char* wn_last_error(const wn_context* ctx);

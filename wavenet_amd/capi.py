@@ -76,6 +76,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch bundles its own libamdhip64 under the same soname as /opt/rocm's; whichever is
+        # mapped first serves the whole process, and a process that ends up with both cannot
+        # see the GPU from the second.  Callers use torch for device memory, so let it go first.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise ImportError(

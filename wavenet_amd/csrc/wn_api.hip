@@ -300,11 +300,7 @@ int wn_set_stream(wn_context* ctx, void* hip_stream) {
     WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->own_stream = false;
-    ctx->stream = (hipStream_t)hip_stream;
-    if (!hip_stream) {
-        WN_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->own_stream = true;
-    }
+    ctx->stream = (hipStream_t)hip_stream;  // NULL is HIP's default stream
     return WN_OK;
 }
 
