@@ -143,6 +143,12 @@ int wn_train_batch(wn_context* ctx, const double* X_dev, int B, int R, int C,
  */
 int wn_sums(wn_context* ctx, double** sums_dev, int* count);
 int wn_get_sums(wn_context* ctx, double* sums_host, int* count); /* synchronises */
+/*
+ * Makes the context keep its sums in caller-owned device memory (at least WN_MAX_TAPS + 2
+ * doubles), e.g. a framework tensor the caller's collective library can reduce directly.
+ * NULL switches back to the context's own buffer.
+ */
+int wn_set_sums_buffer(wn_context* ctx, double* sums_dev);
 
 /*
  * Wavenet::flushBatchQueue_ + update_ + setFilter (src/Wavenet.cxx:717-765, 8-36) on the
@@ -166,6 +172,15 @@ int wn_num_updates(wn_context* ctx, int* steps);  /* synchronises */
  */
 int wn_get_logs(wn_context* ctx, int first, int count, double* filters_host, double* costs_host);
 int wn_clear_logs(wn_context* ctx);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+/*
+ * Brackets the training kernel of every following wn_train_batch with a pair of HIP events on
+ * the context's stream (at most max_records launches; 0 turns it off).  wn_profile_collect
+ * synchronises and returns the kernel durations in milliseconds, oldest first.
+ */
+int wn_profile_begin(wn_context* ctx, int max_records);
+int wn_profile_collect(wn_context* ctx, float* ms_host, int capacity, int* count);
 
 /* ---- data-parallel exchange (RCCL over xGMI) ---------------------------------------------- */
 /*

@@ -47,6 +47,9 @@ SIGNATURES = {
     "wn_train_batch": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "wn_sums": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_int)]),
     "wn_get_sums": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
+    "wn_set_sums_buffer": (C.c_int, [_vp, _vp]),
+    "wn_profile_begin": (C.c_int, [_vp, C.c_int]),
+    "wn_profile_collect": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
     "wn_apply_update": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
     "wn_num_updates": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "wn_get_logs": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp]),
@@ -238,6 +241,19 @@ class Context:
         s = np.empty(n.value)
         self._check(self.lib.wn_get_sums(self._h, s.ctypes.data_as(_dp), C.byref(n)))
         return s
+
+    def set_sums_buffer(self, buf):
+        """buf: device tensor/address of >= WN_MAX_TAPS + 2 doubles, or None for the context's own."""
+        self._check(self.lib.wn_set_sums_buffer(self._h, _addr(buf)))
+
+    def profile_begin(self, max_records):
+        self._check(self.lib.wn_profile_begin(self._h, int(max_records)))
+
+    def profile_collect(self, capacity=4096):
+        ms = (C.c_float * capacity)()
+        n = C.c_int(0)
+        self._check(self.lib.wn_profile_collect(self._h, ms, capacity, C.byref(n)))
+        return np.array(ms[:n.value], dtype=np.float64)
 
     def apply_update(self, batch_total, lambda_sum, alpha, inertia_eff=0.0, wavelet=True):
         self._check(self.lib.wn_apply_update(self._h, float(batch_total), float(lambda_sum), float(alpha),

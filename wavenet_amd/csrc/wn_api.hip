@@ -11,6 +11,7 @@
 #include <map>
 #include <string>
 #include <utility>
+#include <vector>
 
 #include "wavenet_hip.h"
 #include "wn_costfn.h"
@@ -47,6 +48,9 @@ struct wn_context {
     double* partial = nullptr;
     int partial_blocks = 0;
     double* sums = nullptr;
+    double* own_sums = nullptr;
+    std::vector<hipEvent_t> prof_begin, prof_end;
+    int prof_used = 0;
     double* log_filters = nullptr;
     double* log_costs = nullptr;
     void* nccl_lib = nullptr;
@@ -268,7 +272,8 @@ int wn_create(int device, wn_context** out) {
     ctx->partial_blocks = ctx->numCU * 16;
     if (rc == WN_OK) alloc((void**)&ctx->dfilt, sizeof(wn::FilterDev));
     if (rc == WN_OK) alloc((void**)&ctx->partial, (size_t)ctx->partial_blocks * wn::PSTRIDE * sizeof(double));
-    if (rc == WN_OK) alloc((void**)&ctx->sums, wn::PSTRIDE * sizeof(double));
+    if (rc == WN_OK) alloc((void**)&ctx->own_sums, wn::PSTRIDE * sizeof(double));
+    ctx->sums = ctx->own_sums;
     if (rc == WN_OK) alloc((void**)&ctx->log_filters, (size_t)kLogCap * wn::MAXTAPS * sizeof(double));
     if (rc == WN_OK) alloc((void**)&ctx->log_costs, (size_t)kLogCap * sizeof(double));
     if (rc != WN_OK) {
@@ -286,7 +291,9 @@ int wn_destroy(wn_context* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->dfilt);
     (void)hipFree(ctx->partial);
-    (void)hipFree(ctx->sums);
+    (void)hipFree(ctx->own_sums);
+    for (hipEvent_t ev : ctx->prof_begin) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->prof_end) (void)hipEventDestroy(ev);
     (void)hipFree(ctx->log_filters);
     (void)hipFree(ctx->log_costs);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -525,8 +532,14 @@ int wn_train_batch(wn_context* ctx, const double* X, int B, int R, int C, double
     int grid = 0;
     if (B > 0) {
         const size_t shmem = ((size_t)3 * R * C + S.NS + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double) + 16;
+        const bool prof = ctx->prof_used < (int)ctx->prof_begin.size();
+        if (prof) WN_HIP(ctx, hipEventRecord(ctx->prof_begin[ctx->prof_used], ctx->stream));
         rc = launch(ctx, fused_kernel(ctx->NP, KIND_TRAIN, sc), S.T, shmem, B, A, &grid);
         if (rc) return rc;
+        if (prof) {
+            WN_HIP(ctx, hipEventRecord(ctx->prof_end[ctx->prof_used], ctx->stream));
+            ctx->prof_used++;
+        }
         if (grid > ctx->partial_blocks) return fail(ctx, WN_ERR_STATE, "partial buffer too small");
     }
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, ctx->stream, ctx->partial, grid, ctx->N, ctx->sums);
@@ -539,6 +552,47 @@ int wn_sums(wn_context* ctx, double** sums_dev, int* count) {
     if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
     if (sums_dev) *sums_dev = ctx->sums;
     if (count) *count = ctx->N + 2;
+    return WN_OK;
+}
+
+int wn_set_sums_buffer(wn_context* ctx, double* sums_dev) {
+    if (!ctx) return WN_ERR_ARG;
+    WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->sums = sums_dev ? sums_dev : ctx->own_sums;
+    return WN_OK;
+}
+
+int wn_profile_begin(wn_context* ctx, int max_records) {
+    if (!ctx || max_records < 0) return WN_ERR_ARG;
+    WN_HIP(ctx, hipSetDevice(ctx->device));
+    while ((int)ctx->prof_begin.size() < max_records) {
+        hipEvent_t a, b;
+        WN_HIP(ctx, hipEventCreate(&a));
+        WN_HIP(ctx, hipEventCreate(&b));
+        ctx->prof_begin.push_back(a);
+        ctx->prof_end.push_back(b);
+    }
+    while ((int)ctx->prof_begin.size() > max_records) {
+        (void)hipEventDestroy(ctx->prof_begin.back());
+        (void)hipEventDestroy(ctx->prof_end.back());
+        ctx->prof_begin.pop_back();
+        ctx->prof_end.pop_back();
+    }
+    ctx->prof_used = 0;
+    return WN_OK;
+}
+
+int wn_profile_collect(wn_context* ctx, float* ms_host, int capacity, int* count) {
+    if (!ctx || !count || capacity < 0) return WN_ERR_ARG;
+    WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int n = ctx->prof_used < capacity ? ctx->prof_used : capacity;
+    for (int i = 0; i < n; i++) {
+        float ms = 0.f;
+        WN_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_begin[i], ctx->prof_end[i]));
+        if (ms_host) ms_host[i] = ms;
+    }
+    *count = n;
+    ctx->prof_used = 0;
     return WN_OK;
 }
 

@@ -1,0 +1,60 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, examples of a batch
+sharded in contiguous ranges, one all-reduce of N + 2 doubles per batch (RCCL via
+torch.distributed's "nccl" backend), identical update on every replica.
+
+The only coupling between examples in the reference is the batch mean of the gradients and of
+the costs (src/Wavenet.cxx:723-727, 733), so the exchange is the sum of
+[gradient sum (N), sparse-term sum, non-finite count].
+"""
+import os
+
+
+def dist_env():
+    """(rank, local_rank, world_size) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard_range(total, rank, world_size):
+    """Contiguous [begin, end) of `total` examples owned by `rank`; sizes differ by at most one."""
+    base, extra = divmod(total, world_size)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def allreduce_sums(sums, world_size, group=None):
+    """In-place sum over ranks of the per-rank sums tensor (any device torch.distributed supports)."""
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    return sums
+
+
+class DataParallelTrainer:
+    """Drives wn_train_batch -> all-reduce -> wn_apply_update for one rank."""
+
+    def __init__(self, ctx, world_size=1, group=None):
+        import torch
+        from .capi import WN_MAX_TAPS
+        self.ctx = ctx
+        self.world_size = world_size
+        self.group = group
+        self._buf = torch.zeros(WN_MAX_TAPS + 2, dtype=torch.float64, device="cuda")
+        ctx.set_sums_buffer(self._buf)
+
+    def step(self, X_dev, B_local, R, C, lam, alpha, inertia_eff=0.0, wavelet=True, B_total=None):
+        """One batch: B_local examples here, B_total over all ranks (default B_local * world_size)."""
+        if B_total is None:
+            B_total = B_local * self.world_size
+        self.ctx.train_batch(X_dev, B_local, R, C)
+        if self.world_size > 1:
+            n = len_sums(self.ctx)
+            allreduce_sums(self._buf[:n], self.world_size, self.group)
+        self.ctx.apply_update(B_total, lam * B_total, alpha, inertia_eff, wavelet)
+
+    def sums(self):
+        return self._buf[:len_sums(self.ctx)].cpu().numpy()
+
+
+def len_sums(ctx):
+    return ctx.sums_ptr()[1]
