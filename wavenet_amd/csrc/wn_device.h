@@ -337,40 +337,138 @@ __device__ __forceinline__ void sort_run(double* keys, unsigned t) {
     __syncthreads();
 }
 
-template <int LGN, int Q, int KK, int W>
-__device__ __forceinline__ void sort_merge_runs(double* keys, unsigned t) {
-    sort_run<LGN, Q, KK, W>(keys, t);
-    if constexpr (W > 0) sort_merge_runs<LGN, Q, KK, W - 1>(keys, t);
+// ---------------------------------------------------------------------------------------------
+// Wave-local part of the sort.  With e = t*K + r the low Q bits of a key's index are the
+// register, the next 6 bits the lane, the rest the wave.  Sub-stages on lane bits exchange
+// keys between lanes with DPP / ds_swizzle / ds_bpermute (no LDS storage, no barrier): both
+// lanes of a pair fetch the partner's key and keep the minimum or the maximum.  Only the
+// sub-stages on wave bits go through LDS (sort_run on the top window).
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// v of lane (lane ^ M), M a compile-time mask.
+template <int M>
+__device__ __forceinline__ double xlane(double v, int lane) {
+    if constexpr (M == 1) return dpp_mov<0xB1>(v);            // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+    else if constexpr (M == 3) return dpp_mov<0x1B>(v);       // quad_perm [3,2,1,0]
+    else if constexpr (M == 7) return dpp_mov<0x141>(v);      // row_half_mirror
+    else if constexpr (M == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));  // 7 ^ 3
+    else if constexpr (M == 8) return dpp_mov<0x128>(v);      // row_ror:8
+    else if constexpr (M == 15) return dpp_mov<0x140>(v);     // row_mirror
+    else if constexpr (M < 32) {                              // ds_swizzle, bit mode: xor within 32 lanes
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_ds_swizzle(lo, (M << 10) | 0x1F);
+        hi = __builtin_amdgcn_ds_swizzle(hi, (M << 10) | 0x1F);
+        return __hiloint2double(hi, lo);
+    } else {
+        const int addr = (lane ^ M) << 2;
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_ds_bpermute(addr, lo);
+        hi = __builtin_amdgcn_ds_bpermute(addr, hi);
+        return __hiloint2double(hi, lo);
+    }
+}
+
+// Half-cleaners on index bits B..0 (compare e with e ^ 2^b, minimum to the lower index).
+template <int Q, int B>
+__device__ __forceinline__ void wave_clean(double (&v)[1 << Q], int lane) {
+    constexpr int K = 1 << Q;
+    if constexpr (B >= Q) {
+        constexpr int M = 1 << (B - Q);
+        const bool is_lower = (lane & M) == 0;
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+            const double p = xlane<M>(v[r], lane);
+            const bool take = (p < v[r]) == is_lower;
+            v[r] = take ? p : v[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+            if (!(r & (1 << B))) cmpx(v[r], v[r | (1 << B)]);
+        }
+    }
+    if constexpr (B > 0) wave_clean<Q, B - 1>(v, lane);
+}
+
+// First sub-stage of the merge of size 2^KK inside a wave: e against e ^ (2^KK - 1).
+template <int Q, int KK>
+__device__ __forceinline__ void wave_mirror(double (&v)[1 << Q], int lane) {
+    constexpr int K = 1 << Q;
+    constexpr int M = (1 << (KK - Q)) - 1;
+    const bool is_lower = ((lane >> (KK - 1 - Q)) & 1) == 0;
+    double p[K];
+#pragma unroll
+    for (int r = 0; r < K; r++) p[r] = xlane<M>(v[r ^ (K - 1)], lane);
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+        const bool take = (p[r] < v[r]) == is_lower;
+        v[r] = take ? p[r] : v[r];
+    }
 }
 
 template <int LGN, int Q, int KK>
-__device__ __forceinline__ void sort_merges(double* keys, unsigned t) {
-    if constexpr (KK <= LGN) {
-        sort_merge_runs<LGN, Q, KK, SortCfg<LGN, Q>::wtop(KK)>(keys, t);
-        sort_merges<LGN, Q, KK + 1>(keys, t);
+__device__ __forceinline__ void sort_wave_merges(double (&v)[1 << Q], int lane) {
+    constexpr int WL = Q + 6;
+    if constexpr (KK <= LGN && KK <= WL) {
+        wave_mirror<Q, KK>(v, lane);
+        wave_clean<Q, KK - 2>(v, lane);
+        sort_wave_merges<LGN, Q, KK + 1>(v, lane);
     }
+}
+
+template <int LGN, int Q, int KK>
+__device__ __forceinline__ void sort_cross_merges(double (&v)[1 << Q], double* keys, unsigned t, int lane) {
+    using Cfg = SortCfg<LGN, Q>;
+    constexpr int K = 1 << Q;
+    constexpr int WL = Q + 6;
+    if constexpr (KK <= LGN) {
+        constexpr int W = Cfg::wtop(KK);
+        static_assert(Cfg::wbl(W) <= WL, "the top sort window must reach down to the wave-local bits");
+        const unsigned pbase = swz(t * K);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < K; r++) keys[pbase ^ swz_c((unsigned)r)] = v[r];
+        __syncthreads();
+        sort_run<LGN, Q, KK, W>(keys, t);  // ends with a barrier
+#pragma unroll
+        for (int r = 0; r < K; r++) v[r] = keys[pbase ^ swz_c((unsigned)r)];
+        wave_clean<Q, Cfg::wbl(W) - 1>(v, lane);
+        sort_cross_merges<LGN, Q, KK + 1>(v, keys, t, lane);
+    }
+}
+
+// Sorts T*K keys: v[r] is key t*K + r on entry; on exit keys[e] holds the e-th smallest.
+template <int LGN, int Q>
+__device__ __forceinline__ void sort_full(double (&v)[1 << Q], double* keys, unsigned t) {
+    constexpr int K = 1 << Q;
+    constexpr int WL = Q + 6;
+    const int lane = (int)(t & 63u);
+    sort_regs<Q>(v);
+    sort_wave_merges<LGN, Q, Q + 1>(v, lane);
+    sort_cross_merges<LGN, Q, WL + 1>(v, keys, t, lane);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < K; r++) keys[t * K + r] = v[r];  // final order is stored unswizzled
+    __syncthreads();
 }
 
 // Number of keys strictly below v in the sorted buffer (v itself is in the buffer).
 template <int LGN>
-__device__ __forceinline__ unsigned lower_bound_swz(const double* keys, double v) {
+__device__ __forceinline__ unsigned lower_bound_sorted(const double* keys, double v) {
     unsigned pos = 0;
 #pragma unroll
     for (int s = LGN - 1; s >= 0; s--) {
         const unsigned step = 1u << s;
-        if (keys[swz(pos + step - 1)] < v) pos += step;
+        if (keys[pos + step - 1] < v) pos += step;
     }
-    return pos;
-}
-template <int LGN>
-__device__ __forceinline__ unsigned upper_bound_swz(const double* keys, double v) {
-    unsigned pos = 0;
-#pragma unroll
-    for (int s = LGN - 1; s >= 0; s--) {
-        const unsigned step = 1u << s;
-        if (keys[swz(pos + step - 1)] <= v) pos += step;
-    }
-    if (keys[swz(pos)] <= v) pos++;
     return pos;
 }
 
@@ -411,13 +509,8 @@ __device__ __forceinline__ double gini_phase(double* bufY, int n, double* red, i
         double sv[K];
 #pragma unroll
         for (int r = 0; r < K; r++) sv[r] = kv[r];
-        sort_regs<Q>(sv);
-        const unsigned pbase = swz(e0);
-#pragma unroll
-        for (int r = 0; r < K; r++) bufY[pbase ^ swz_c((unsigned)r)] = sv[r];
+        sort_full<LGN, Q>(sv, bufY, (unsigned)tid);
     }
-    __syncthreads();
-    sort_merges<LGN, Q, Q + 1>(bufY, (unsigned)tid);
 
     unsigned lb[K];
     bool tie = false;
@@ -425,8 +518,8 @@ __device__ __forceinline__ double gini_phase(double* bufY, int n, double* red, i
     for (int r = 0; r < K; r++) {
         lb[r] = 0;
         if (e0 + r < (unsigned)n) {
-            lb[r] = lower_bound_swz<LGN>(bufY, kv[r]);
-            if (kv[r] != 0.0 && lb[r] + 1 < (1u << LGN) && bufY[swz(lb[r] + 1)] == kv[r]) tie = true;
+            lb[r] = lower_bound_sorted<LGN>(bufY, kv[r]);
+            if (kv[r] != 0.0 && lb[r] + 1 < (1u << LGN) && bufY[lb[r] + 1] == kv[r]) tie = true;
         }
     }
     if (tie) *flag = 1;
@@ -440,24 +533,23 @@ __device__ __forceinline__ double gini_phase(double* bufY, int n, double* red, i
         uint32_t* words = reinterpret_cast<uint32_t*>(bufY);
 #pragma unroll
         for (int r = 0; r < K; r++) {
-            mine[r] = false;
             ub[r] = lb[r] + 1;
-            if (e0 + r < (unsigned)n && kv[r] != 0.0) {
-                ub[r] = upper_bound_swz<LGN>(bufY, kv[r]);
-                mine[r] = (ub[r] - lb[r] > 1);
+            mine[r] = e0 + r < (unsigned)n && kv[r] != 0.0 && ub[r] < (1u << LGN) && bufY[ub[r]] == kv[r];
+            if (mine[r]) {
+                do { ub[r]++; } while (ub[r] < (1u << LGN) && bufY[ub[r]] == kv[r]);
             }
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < K; r++) {
-            if (mine[r]) words[2 * swz(lb[r])] = 0u;
+            if (mine[r]) words[2 * lb[r]] = 0u;
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < K; r++) {
             if (mine[r]) {
-                const unsigned slot = 1u + atomicAdd(&words[2 * swz(lb[r])], 1u);
-                words[2 * swz(lb[r] + (slot >> 1)) + (slot & 1u)] = e0 + r;
+                const unsigned slot = 1u + atomicAdd(&words[2 * lb[r]], 1u);
+                words[2 * lb[r] + slot] = e0 + r;
             }
         }
         __syncthreads();
@@ -467,7 +559,7 @@ __device__ __forceinline__ double gini_phase(double* bufY, int n, double* red, i
                 const unsigned mult = ub[r] - lb[r];
                 unsigned below = 0;
                 for (unsigned s = 1; s <= mult; s++) {
-                    const unsigned other = words[2 * swz(lb[r] + (s >> 1)) + (s & 1u)];
+                    const unsigned other = words[2 * lb[r] + s];
                     below += (other < e0 + r) ? 1u : 0u;
                 }
                 lb[r] += below;
