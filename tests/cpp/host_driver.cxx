@@ -1,0 +1,142 @@
+// Test driver for the host C++ layer (wavenet::Wavenet / Coach / CostFunctions / operators).
+// Reads doubles from a binary file, runs one scenario, prints named arrays as text
+// ("name count v0 v1 ...", %.17g) for tests/test_host_cpp.py to compare with the oracle.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "Wavenet/Coach.h"
+#include "Wavenet/Generators.h"
+#include "Wavenet/Wavenet.h"
+
+using namespace wavenet;
+
+static std::vector<double> readAll(const char* path) {
+    std::vector<double> v;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) { std::perror(path); std::exit(2); }
+    double buf[4096];
+    size_t got;
+    while ((got = std::fread(buf, sizeof(double), 4096, f)) > 0) v.insert(v.end(), buf, buf + got);
+    std::fclose(f);
+    return v;
+}
+
+static void dump(const char* name, const double* p, size_t n) {
+    std::printf("%s %zu", name, n);
+    for (size_t i = 0; i < n; i++) std::printf(" %.17g", p[i]);
+    std::printf("\n");
+}
+static void dump(const char* name, const Mat& M) { dump(name, M.memptr(), M.n_elem); }
+static void dumpLogs(Wavenet& w) {
+    std::vector<double> flat;
+    for (const Col& f : w.filterLog()) flat.insert(flat.end(), f.memptr(), f.memptr() + f.n_elem);
+    dump("filterLog", flat.data(), flat.size());
+    dump("costLog", w.costLog().data(), w.costLog().size());
+    dump("filter", w.filter());
+    dump("momentum", w.momentum());
+    double misc[3] = {w.lambda(), w.alpha(), (double)w.batchSize()};
+    dump("misc", misc, 3);
+}
+
+// exposes the protected transform methods, as a derived probe class would for the reference
+struct Probe : public Wavenet {
+    using Wavenet::backpropagate_;
+    using Wavenet::forward_;
+    using Wavenet::inverse_;
+};
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    const std::string mode = argv[1];
+    if (mode == "ops") {
+        const unsigned R = std::atoi(argv[2]), C = std::atoi(argv[3]), N = std::atoi(argv[4]);
+        std::vector<double> in = readAll(argv[5]);
+        const size_t n = (size_t)R * C;
+        Probe w;
+        if (!w.setFilter(Col(N, in.data()))) return 3;
+        Mat X(R, C, in.data() + N), D(R, C, in.data() + N + n);
+        Activations2D_t A = w.forward_(X);
+        Mat Y = coeffsFromActivations(A);
+        dump("Y", Y);
+        dump("Xinv", w.inverse_(Y));
+        dump("grad", w.backpropagate_(D, A));
+        double c = w.cost(Y), s = SparseTerm(Y);
+        dump("cost", &c, 1);
+        dump("sparse", &s, 1);
+        dump("sparseDeriv", SparseTermDeriv(Y));
+        double r = RegTerm(w.filter());
+        dump("reg", &r, 1);
+        dump("regDeriv", RegTermDeriv(w.filter()));
+        dump("lowpass", LowpassOperator(w.filter(), 2));
+        dump("highpass", HighpassOperator(w.filter(), 2));
+        if (C == 1) {
+            Col x(R, X.memptr()), d(R, D.memptr());
+            Activations1D_t a1 = w.forward_(x);
+            dump("coeffs1d", coeffsFromActivations(a1));
+            std::vector<Col> out = w.backpropagate_(d, a1);
+            dump("grad1d", out[0]);
+            dump("din1d", out[1]);
+            dump("inv1d", w.inverse_(coeffsFromActivations(a1)));
+        }
+        dump("basis", w.basisFunction(R, C, R > 1 ? 1 : 0, C > 1 ? 1 : 0));
+        // error behaviour: odd filter and non radix-2 input are refused
+        double flags[3] = {(double)w.setFilter(Col({1., 2., 3.})), (double)w.setFilter(Col()), (double)w.train(Mat(3, 1))};
+        dump("refused", flags, 3);
+        return 0;
+    }
+    if (mode == "train") {
+        const unsigned R = std::atoi(argv[2]), C = std::atoi(argv[3]), N = std::atoi(argv[4]), E = std::atoi(argv[5]);
+        const unsigned batch = std::atoi(argv[6]);
+        const double inertia = std::atof(argv[7]);
+        const bool batched = std::atoi(argv[8]) != 0;
+        std::vector<double> in = readAll(argv[9]);
+        const size_t n = (size_t)R * C;
+        Wavenet w(10.0, 1e-3);
+        w.setBatchSize(batch);
+        if (inertia > 0) w.setInertia(inertia);
+        if (!w.setFilter(Col(N, in.data()))) return 3;
+        if (batched) {
+            // an odd split exercises the pending-queue path between device rounds
+            const unsigned first = E / 3;
+            if (!w.trainBatch(in.data() + N, first, R, C)) return 4;
+            if (!w.trainBatch(in.data() + N + first * n, E - first, R, C)) return 4;
+        } else {
+            for (unsigned e = 0; e < E; e++) {
+                if (!w.train(Mat(R, C, in.data() + N + e * n))) return 4;
+            }
+        }
+        dumpLogs(w);
+        return 0;
+    }
+    if (mode == "coach") {
+        const unsigned R = std::atoi(argv[2]), C = std::atoi(argv[3]), N = std::atoi(argv[4]);
+        const int events = std::atoi(argv[5]);
+        const unsigned epochs = std::atoi(argv[6]), batch = std::atoi(argv[7]), flags = std::atoi(argv[8]);
+        const unsigned long long seed = std::strtoull(argv[9], nullptr, 10);
+        const double target = std::atof(argv[10]);
+        std::vector<double> in = readAll(argv[11]);
+        Wavenet w(10.0, 1e-3);
+        w.setBatchSize(batch);
+        UniformGenerator gen;
+        gen.setSeed(seed);
+        if (!gen.setShape({R, C})) return 3;
+        Coach coach("driver");
+        coach.setWavenet(&w);
+        coach.setGenerator(&gen);
+        coach.setNumEvents(events);
+        coach.setNumEpochs(epochs);
+        coach.setNumCoeffs(N);
+        coach.setInitialFilter(Col(N, in.data()));
+        coach.setUseAdaptiveLearningRate(flags & 1u);
+        coach.setUseAdaptiveBatchSize((flags >> 1) & 1u);
+        coach.setUseSimulatedAnnealing((flags >> 2) & 1u);
+        if (target > 0) coach.setTargetPrecision(target);
+        if (!coach.run()) return 4;
+        dumpLogs(w);
+        return 0;
+    }
+    return 2;
+}

@@ -1,0 +1,115 @@
+"""The host C++ layer (wavenet::Wavenet, Coach, CostFunctions, Lowpass/HighpassOperator, generators in
+wavenet_amd/host) driven through tests/cpp/host_driver and compared with the CPU oracle.  The driver
+is a plain C++ program: it reaches the GPU only through the C ABI of include/wavenet_hip.h."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import filters as F
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "tests", "cpp", "host_driver")
+
+
+def run_driver(args, arrays):
+    assert os.path.exists(DRIVER), "build it with make -C tests/cpp (done by __graft_entry__.build())"
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in arrays]).tofile(f)
+        path = f.name
+    try:
+        res = subprocess.run([DRIVER] + [str(a) for a in args] + [path], capture_output=True, text=True, timeout=300)
+    finally:
+        os.unlink(path)
+    assert res.returncode == 0, (res.returncode, res.stdout[-500:], res.stderr[-2000:])
+    out = {}
+    for line in res.stdout.splitlines():
+        parts = line.split()
+        out[parts[0]] = np.array([float(v) for v in parts[2:]])
+        assert len(out[parts[0]]) == int(parts[1])
+    return out, res.stderr
+
+
+def colmajor(X):
+    return np.asarray(X).reshape(-1, order="F")
+
+
+@pytest.mark.parametrize("R,C,N", [(16, 8, 4), (64, 1, 6), (8, 8, 16), (64, 64, 2)])
+def test_wavenet_methods(oracle, R, C, N):
+    rng = np.random.default_rng(R + C + N)
+    a = F.random_filter(N, 2) if N == 6 else F.perturbed(F.daubechies(N), 1e-2, 1)
+    X, D = rng.random((R, C)), rng.standard_normal((R, C))
+    out, err = run_driver(["ops", R, C, N], [a, colmajor(X), colmajor(D)])
+    w = oracle.Wavenet()
+    w.set_filter(a)
+    AR, AC, Y = w.forward_2d(X)
+    tol = dict(rtol=1e-10, atol=1e-12)
+    assert np.allclose(out["Y"], colmajor(Y), **tol)
+    assert np.allclose(out["Xinv"], colmajor(w.inverse_2d(Y)), **tol)
+    assert np.allclose(out["grad"], w.backprop_2d(D, AR, AC), **tol)
+    assert out["cost"][0] == pytest.approx(w.cost(Y), rel=1e-12)
+    assert out["sparse"][0] == pytest.approx(oracle.sparse_term(Y), rel=1e-12)
+    assert np.allclose(out["sparseDeriv"], colmajor(oracle.sparse_term_deriv(Y)), **tol)
+    assert out["reg"][0] == oracle.reg_term(a)
+    assert np.array_equal(out["regDeriv"], oracle.reg_term_deriv(a))
+    assert np.allclose(out["lowpass"], colmajor(oracle.lowpass_operator(a, 2)), rtol=0, atol=1e-15)
+    assert np.allclose(out["highpass"], colmajor(oracle.highpass_operator(a, 2)), rtol=0, atol=1e-15)
+    onehot = np.zeros((R, C))
+    onehot[1 if R > 1 else 0, 1 if C > 1 else 0] = 1.0
+    assert np.allclose(out["basis"], colmajor(w.inverse_2d(onehot)), **tol)
+    assert list(out["refused"]) == [0.0, 0.0, 0.0]
+    assert "multiple of 2" in err and "empty" in err and "radix 2" in err
+    if C == 1:
+        LO, HI = w.forward_1d(X[:, 0])
+        assert np.allclose(out["coeffs1d"], w.coeffs_1d(LO, HI), **tol)
+        g, din = w.backprop_1d(D[:, 0], LO, HI)
+        assert np.allclose(out["grad1d"], g, **tol)
+        assert np.allclose(out["din1d"], din, **tol)
+        assert np.allclose(out["inv1d"], X[:, 0], rtol=0, atol=1.0) and np.allclose(
+            out["inv1d"], w.inverse_1d(w.coeffs_1d(LO, HI)), **tol)
+
+
+@pytest.mark.parametrize("batched", [0, 1])
+@pytest.mark.parametrize("R,C,N,E,batch,inertia", [(16, 16, 4, 50, 8, 0.0), (32, 1, 2, 40, 1, 0.5), (8, 8, 16, 45, 10, 0.9)])
+def test_train_matches_oracle(oracle, R, C, N, E, batch, inertia, batched):
+    rng = np.random.default_rng(E + N)
+    a = F.perturbed(F.daubechies(N), 1e-2, 2)
+    X = rng.random((E, R, C))
+    flat = np.concatenate([colmajor(x) for x in X])
+    out, _ = run_driver(["train", R, C, N, E, batch, inertia, batched], [a, flat])
+    w = oracle.Wavenet(lam=10.0, alpha=1e-3)
+    w.set_batch_size(batch)
+    w.set_inertia(inertia)
+    w.set_filter(a)
+    for x in X:
+        w.train(x)
+    assert np.allclose(out["filterLog"].reshape(-1, N), w.filter_log(), rtol=1e-9, atol=0)
+    assert np.allclose(out["costLog"], w.cost_log(), rtol=1e-9, atol=1e-15)
+    assert np.allclose(out["momentum"], w.momentum(), rtol=1e-8, atol=1e-15)
+
+
+@pytest.mark.parametrize("flags,events,epochs,batch,target", [(0, 64, 1, 8, -1), (4, 60, 2, 4, -1), (3, 400, 1, 2, -1),
+                                                              (1, 600, 1, 2, 5e-5)])
+def test_coach_run_matches_oracle(oracle, flags, events, epochs, batch, target):
+    """Coach::run with the deterministic UniformGenerator against the oracle's event loop: fixed schedule,
+    simulated annealing over two epochs, adaptive learning rate + batch size, and early stop."""
+    from wavenet_amd import generators as G
+    R, C, N, seed = 8, 8, 4, 42
+    a = F.perturbed(F.DB4, 5e-2, 5)
+    out, _ = run_driver(["coach", R, C, N, events, epochs, batch, flags, seed, target], [a])
+    X = G.uniform(events, R, C, seed=seed)   # the C++ generator hashes (seed, event, pixel) identically
+    w = oracle.Wavenet(lam=10.0, alpha=1e-3)
+    w.set_batch_size(batch)
+    w.coach_run(a, X, events, num_epochs=epochs, adaptive_lr=bool(flags & 1), adaptive_batch=bool(flags & 2),
+                annealing=bool(flags & 4), target_precision=target)
+    ofl, ocl = w.filter_log(), w.cost_log()
+    fl = out["filterLog"].reshape(-1, N)
+    assert fl.shape == ofl.shape
+    assert np.allclose(fl, ofl, rtol=1e-9, atol=0)
+    assert np.allclose(out["costLog"], ocl, rtol=1e-9, atol=1e-15)
+    lam, alpha, bs = out["misc"]
+    assert lam == pytest.approx(w.lam(), rel=1e-14) and alpha == w.alpha() and bs == w.batch_size()

@@ -1,0 +1,144 @@
+// wavenet::Wavenet with the public surface of the reference class (include/Wavenet/Wavenet.h:76-860)
+// on top of the C ABI in include/wavenet_hip.h: the transforms, the sparsity gradient and the
+// backpropagation run as HIP kernels; the object keeps the reference's host-side state (filter,
+// momentum, batch queue, filter log, cost log) and semantics.
+//
+// Not carried over: save()/load() (Snapshot text files) and everything under USE_ROOT.
+#ifndef WAVENET_WAVENET_H
+#define WAVENET_WAVENET_H
+
+#include <string>
+#include <vector>
+
+#include "Wavenet/CostFunctions.h"
+#include "Wavenet/HighpassOperator.h"
+#include "Wavenet/Logger.h"
+#include "Wavenet/LowpassOperator.h"
+#include "Wavenet/Matrix.h"
+#include "Wavenet/Utilities.h"
+
+struct wn_context;
+
+namespace wavenet {
+
+class DeviceSession;  // device buffers and the wn_context of one Wavenet object
+
+class Wavenet {
+public:
+    Wavenet();
+    Wavenet(const double& lambda);
+    Wavenet(const double& lambda, const double& alpha);
+    Wavenet(const Wavenet& other);  // copies the learning parameters and the filter (Wavenet.h:91-97)
+    Wavenet& operator=(const Wavenet&) = delete;
+    ~Wavenet();
+
+    /// Get method(s).
+    double lambda() const { return m_lambda; }
+    double alpha() const { return m_alpha; }
+    double inertia() const { return m_inertia; }
+    double inertiaTimeScale() const { return m_inertiaTimeScale; }
+    Col filter() const { return m_filter; }
+    Col momentum() const { return m_momentum; }
+    int batchSize() const { return m_batchSize; }
+    bool wavelet() const { return m_wavelet; }
+    std::vector<Col>& filterLog() { return m_filterLog; }
+    void clearFilterLog() { m_filterLog.clear(); }
+    std::vector<double>& costLog() { return m_costLog; }
+    void clearCostLog() { m_costLog.assign(1, 0.); }
+    double firstCost() const;
+    double lastCost() const;
+
+    /// Set method(s).
+    bool setLambda(const double& lambda);
+    bool setAlpha(const double& alpha);
+    bool setInertia(const double& inertia);
+    bool setInertiaTimeScale(const double& inertiaTimeScale);
+    bool setFilter(const Col& filter);
+    bool setMomentum(const Col& momentum);
+    bool setBatchSize(const unsigned& batchSize) { m_batchSize = batchSize; return true; }
+    bool doWavelet(const bool& wavelet) { m_wavelet = wavelet; return true; }
+    // GPU to run on (default 0); takes effect before the first device call.
+    void setDevice(int device) { m_device = device; }
+
+    void print() const;
+
+    /// High-level learning method(s).
+    // One example, exactly the reference's train (src/Wavenet.cxx:184-242).
+    bool train(Mat X);
+    // B examples (column-major, contiguous, host memory) in arrival order, same result as B calls of
+    // train(): whole batches run on the device back to back; a trailing partial batch is left in
+    // the batch queue.  lambdas (optional, B values) is the regularisation constant per example
+    // for Coach's annealing; otherwise lambda() is used.
+    bool trainBatch(const double* X, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas = nullptr);
+    void clear();
+
+    /// High-level cost method(s).
+    double cost(const Col& y);
+    double cost(const Mat& Y);
+    std::vector<Mat> costMap(const std::vector<Mat>& X, const double& range, const unsigned& Ndiv);
+
+    /// Basis function method(s).
+    Mat basisFunction1D(const unsigned& nRows, const unsigned& irow);
+    Mat basisFunction2D(const unsigned& nRows, const unsigned& nCols, const unsigned& irow, const unsigned& icol);
+    Mat basisFunction(const unsigned& nRows, const unsigned& nCols, const unsigned& irow, const unsigned& icol);
+
+    /// The transform methods by their plain names.
+    Activations1D_t forward(const Col& x) { return forward_(x); }
+    Activations2D_t forward(const Mat& X) { return forward_(X); }
+    Col inverse(const Col& y) { return inverse_(y); }
+    Mat inverse(const Mat& Y) { return inverse_(Y); }
+    std::vector<Col> backpropagate(const Col& delta, Activations1D_t activations) { return backpropagate_(delta, activations); }
+    Col backpropagate(const Mat& Delta, Activations2D_t Activations) { return backpropagate_(Delta, Activations); }
+    void update(const Col& gradient) { update_(gradient); }
+
+protected:
+    /// 1D wavenet transform method(s).
+    Activations1D_t forward_(const Col& x);
+    Col inverse_(const Col& y);
+    // {gradient on the filter coefficients, errors on the input}
+    std::vector<Col> backpropagate_(const Col& delta, Activations1D_t activations);
+
+    /// 2D wavenet transform method(s).
+    Activations2D_t forward_(const Mat& X);
+    Mat inverse_(const Mat& Y);
+    Col backpropagate_(const Mat& Delta, Activations2D_t Activations);
+
+    /// Low-level learning method(s).
+    void flushBatchQueue_();
+    void addMomentum_(const Col& gradient);
+    void scaleMomentum_(const double& factor);
+    void update_(const Col& gradient);
+    double effectiveInertia_(unsigned steps) const;
+
+private:
+    DeviceSession& device_();
+    bool checkShape_(unsigned nRows, unsigned nCols) const;
+    // forward + sparsity gradient + backpropagation of `count` examples already on the device,
+    // per-example results into the batch queue and the cost log (the slow, exact path of train()).
+    bool queueExamples_(const double* X_dev, unsigned count, unsigned nRows, unsigned nCols, const double* lambdas);
+
+    double m_lambda = 10.0;
+    double m_alpha = 0.001;
+    double m_inertia = 0.;
+    double m_inertiaTimeScale = 0.;
+    Col m_filter;
+    Col m_momentum;
+    unsigned m_batchSize = 1;
+    std::vector<Col> m_batchQueue;
+    std::vector<Col> m_filterLog;
+    std::vector<double> m_costLog = {0};
+    bool m_wavelet = true;
+    int m_device = 0;
+    DeviceSession* m_session = nullptr;
+};
+
+template <class T>
+inline T frobeniusProduct(const Mat& A, const Mat& B) {
+    T acc = 0;
+    for (std::size_t i = 0; i < A.n_elem; i++) acc += A(i) * B(i);
+    return acc;
+}
+
+}  // namespace wavenet
+
+#endif

@@ -1,0 +1,501 @@
+#include "Wavenet/Wavenet.h"
+
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstring>
+#include <string>
+
+#include "wavenet_hip.h"
+
+namespace wavenet {
+
+// -------------------------------------------------------------------------------------------------
+// Device side of one Wavenet object: the wn_context and grow-only device buffers.
+// -------------------------------------------------------------------------------------------------
+class DeviceSession {
+public:
+    enum Slot { X = 0, Y, PROW, Y1, PCOL, DELTA, GRAD, S, NSLOTS };
+
+    explicit DeviceSession(int device) {
+        if (wn_create(device, &ctx) != WN_OK) {
+            ERROR("Cannot create a device context on GPU %d: %s", device, wn_last_error(nullptr));
+            ctx = nullptr;
+        }
+        for (int i = 0; i < NSLOTS; i++) { m_buf[i] = nullptr; m_cap[i] = 0; }
+    }
+    ~DeviceSession() {
+        if (!ctx) return;
+        for (int i = 0; i < NSLOTS; i++) {
+            if (m_buf[i]) wn_free(ctx, m_buf[i]);
+        }
+        wn_destroy(ctx);
+    }
+    double* buf(Slot slot, std::size_t doubles) {
+        if (m_cap[slot] < doubles) {
+            if (m_buf[slot]) wn_free(ctx, m_buf[slot]);
+            m_buf[slot] = nullptr;
+            if (wn_malloc(ctx, (void**)&m_buf[slot], doubles * sizeof(double)) != WN_OK) {
+                ERROR("%s", wn_last_error(ctx));
+                m_cap[slot] = 0;
+                return nullptr;
+            }
+            m_cap[slot] = doubles;
+        }
+        return m_buf[slot];
+    }
+    bool ok(int status) const {
+        if (status != WN_OK) ERROR("%s (%s)", wn_last_error(ctx), wn_status_string(status));
+        return status == WN_OK;
+    }
+    bool up(double* dst, const double* src, std::size_t n) { return dst && ok(wn_memcpy_h2d(ctx, dst, src, n * sizeof(double))); }
+    bool down(double* dst, const double* src, std::size_t n) { return src && ok(wn_memcpy_d2h(ctx, dst, src, n * sizeof(double))); }
+
+    wn_context* ctx = nullptr;
+
+private:
+    double* m_buf[NSLOTS];
+    std::size_t m_cap[NSLOTS];
+};
+
+// -------------------------------------------------------------------------------------------------
+
+Wavenet::Wavenet() {}
+Wavenet::Wavenet(const double& lambda) : m_lambda(lambda) {}
+Wavenet::Wavenet(const double& lambda, const double& alpha) : m_lambda(lambda), m_alpha(alpha) {}
+Wavenet::Wavenet(const Wavenet& other)
+    : m_lambda(other.m_lambda), m_alpha(other.m_alpha), m_inertia(other.m_inertia),
+      m_inertiaTimeScale(other.m_inertiaTimeScale), m_filter(other.m_filter), m_device(other.m_device) {}
+Wavenet::~Wavenet() { delete m_session; }
+
+DeviceSession& Wavenet::device_() {
+    if (!m_session) {
+        m_session = new DeviceSession(m_device);
+        if (m_session->ctx && !m_filter.is_empty()) {
+            m_session->ok(wn_set_filter(m_session->ctx, m_filter.memptr(), (int)m_filter.n_elem));
+            if (m_momentum.n_elem == m_filter.n_elem)
+                m_session->ok(wn_set_momentum(m_session->ctx, m_momentum.memptr(), (int)m_momentum.n_elem));
+        }
+    }
+    return *m_session;
+}
+
+/// Set method(s).
+bool Wavenet::setLambda(const double& lambda) { assert(lambda >= 0); m_lambda = lambda; return true; }
+bool Wavenet::setAlpha(const double& alpha) { assert(alpha > 0); m_alpha = alpha; return true; }
+bool Wavenet::setInertia(const double& inertia) { assert(inertia >= 0 && inertia < 1); m_inertia = inertia; return true; }
+bool Wavenet::setInertiaTimeScale(const double& inertiaTimeScale) {
+    assert(inertiaTimeScale > 0);
+    m_inertiaTimeScale = inertiaTimeScale;
+    return true;
+}
+
+bool Wavenet::setFilter(const Col& filter) {
+    if (filter.is_empty()) {
+        WARNING("Input filter is empty.");
+        return false;
+    }
+    if (filter.n_rows % 2) {
+        WARNING("Input filter length is not a multiple of 2.");
+        return false;
+    }
+    if (filter.n_elem > WN_MAX_TAPS) {
+        WARNING("Input filter has %d coefficients; at most %d are supported.", (int)filter.n_elem, WN_MAX_TAPS);
+        return false;
+    }
+    m_filter = filter;
+    m_filterLog.push_back(m_filter);
+    if (m_momentum.n_elem != m_filter.n_elem) m_momentum.zeros(m_filter.n_elem);
+    if (m_session && m_session->ctx) {
+        // stands for clearCachedOperators_(): the device taps are what the operators were built from
+        if (!m_session->ok(wn_set_filter(m_session->ctx, m_filter.memptr(), (int)m_filter.n_elem))) return false;
+    }
+    return true;
+}
+
+bool Wavenet::setMomentum(const Col& momentum) {
+    assert(momentum.size() == m_filter.size());
+    m_momentum = momentum;
+    if (m_session && m_session->ctx)
+        return m_session->ok(wn_set_momentum(m_session->ctx, m_momentum.memptr(), (int)m_momentum.n_elem));
+    return true;
+}
+
+/// Get method(s).
+double Wavenet::firstCost() const { return m_costLog.size() > 0 ? m_costLog[0] : -1.; }
+
+double Wavenet::lastCost() const {
+    if (m_costLog.size() > 0) {
+        if (m_costLog.back() > 0) {
+            if (m_batchQueue.size() > 0) return m_costLog.back() / float(m_batchQueue.size());
+            return m_costLog.back();
+        } else if (m_costLog.size() > 1) {
+            return m_costLog[m_costLog.size() - 2];
+        }
+    }
+    return -1.;
+}
+
+void Wavenet::print() const {
+    std::string f, p;
+    for (std::size_t i = 0; i < m_filter.n_elem; i++) f += (i ? ", " : "") + std::to_string(m_filter(i));
+    for (std::size_t i = 0; i < m_momentum.n_elem; i++) p += (i ? ", " : "") + std::to_string(m_momentum(i));
+    std::printf("Wavenet: lambda %g, alpha %g, inertia %g (time scale %g), batch size %u, queue %zu\n", m_lambda,
+                m_alpha, m_inertia, m_inertiaTimeScale, m_batchSize, m_batchQueue.size());
+    std::printf("  filter   : [%s]\n  momentum : [%s]\n", f.c_str(), p.c_str());
+}
+
+bool Wavenet::checkShape_(unsigned nRows, unsigned nCols) const {
+    if (m_filter.is_empty()) {
+        ERROR("No filter set.");
+        return false;
+    }
+    if (!isRadix2(nRows) || !isRadix2(nCols)) {
+        ERROR("Shape {%u, %u} is not radix 2.", nRows, nCols);
+        return false;
+    }
+    return true;
+}
+
+/// High-level learning method(s).
+bool Wavenet::queueExamples_(const double* X_dev, unsigned count, unsigned nRows, unsigned nCols, const double* lambdas) {
+    DeviceSession& dev = device_();
+    const int N = (int)m_filter.n_elem;
+    double* dG = dev.buf(DeviceSession::GRAD, (std::size_t)count * N);
+    double* dS = dev.buf(DeviceSession::S, count);
+    if (!dG || !dS) return false;
+    if (!dev.ok(wn_train_batch(dev.ctx, X_dev, (int)count, (int)nRows, (int)nCols, dG, dS))) return false;
+    std::vector<double> G((std::size_t)count * N), S(count);
+    if (!dev.down(G.data(), dG, G.size()) || !dev.down(S.data(), dS, count)) return false;
+
+    const Col regDeriv = RegTermDeriv(m_filter, m_wavelet);
+    const double reg = RegTerm(m_filter, m_wavelet);
+    for (unsigned e = 0; e < count; e++) {
+        const double lambda = lambdas ? lambdas[e] : m_lambda;
+        Col gradientCombined(N);
+        for (int k = 0; k < N; k++) gradientCombined(k) = G[(std::size_t)e * N + k] + lambda * regDeriv(k);
+        m_batchQueue.push_back(gradientCombined);
+        m_costLog.back() += S[e] + lambda * reg;
+        if (lambdas) m_lambda = lambda;
+        if (m_batchQueue.size() >= m_batchSize) flushBatchQueue_();
+        // the filter only changes at a flush, and a flush only happens on the last queued example
+        // of this call (callers size `count` accordingly)
+    }
+    return true;
+}
+
+bool Wavenet::train(Mat X) {
+    return trainBatch(X.memptr(), 1, (unsigned)X.n_rows, (unsigned)X.n_cols);
+}
+
+bool Wavenet::trainBatch(const double* X, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas) {
+    if (!checkShape_(nRows, nCols)) return false;
+    if (B == 0) return true;
+    DeviceSession& dev = device_();
+    if (!dev.ctx) return false;
+    const std::size_t n = (std::size_t)nRows * nCols;
+    const int N = (int)m_filter.n_elem;
+    double* dX = dev.buf(DeviceSession::X, (std::size_t)B * n);
+    if (!dev.up(dX, X, (std::size_t)B * n)) return false;
+
+    unsigned done = 0;
+    while (done < B) {
+        const unsigned room = m_batchSize > m_batchQueue.size() ? m_batchSize - (unsigned)m_batchQueue.size() : 1;
+        if (m_batchQueue.empty() && B - done >= m_batchSize && m_batchSize >= 1) {
+            // whole batches back to back on the device: train kernel, batch reduction, update kernel
+            // (at most 8192 per round trip: the device keeps the last 16384 log entries)
+            const unsigned nb = std::min((B - done) / m_batchSize, 8192u);
+            const int firstLog = [&] { int s = 0; wn_num_updates(dev.ctx, &s); return s; }();
+            for (unsigned b = 0; b < nb; b++) {
+                const double* Xb = dX + (std::size_t)(done + b * m_batchSize) * n;
+                double lambdaSum = 0;
+                for (unsigned e = 0; e < m_batchSize; e++)
+                    lambdaSum += lambdas ? lambdas[done + b * m_batchSize + e] : m_lambda;
+                const unsigned steps = (unsigned)m_costLog.size() - 1 + b;
+                if (!dev.ok(wn_train_batch(dev.ctx, Xb, (int)m_batchSize, (int)nRows, (int)nCols, nullptr, nullptr))) return false;
+                if (!dev.ok(wn_apply_update(dev.ctx, (double)m_batchSize, lambdaSum, m_alpha, effectiveInertia_(steps), m_wavelet)))
+                    return false;
+            }
+            // bring the logs and the state back
+            std::vector<double> F((std::size_t)nb * N), C(nb);
+            if (!dev.ok(wn_get_logs(dev.ctx, firstLog, (int)nb, F.data(), C.data()))) return false;
+            for (unsigned b = 0; b < nb; b++) {
+                m_filterLog.push_back(Col(N, F.data() + (std::size_t)b * N));
+                m_costLog.back() = C[b];
+                m_costLog.push_back(0);
+                if (!std::isfinite(C[b])) WARNING("Non-finite cost at update %zu: diverging solution?", m_costLog.size() - 1);
+            }
+            m_filter = m_filterLog.back();
+            int nn = N;
+            if (!dev.ok(wn_get_momentum(dev.ctx, m_momentum.memptr(), &nn))) return false;
+            if (lambdas) m_lambda = lambdas[done + nb * m_batchSize - 1];
+            done += nb * m_batchSize;
+        } else {
+            // fill the pending batch (or a trailing partial one) example by example
+            const unsigned count = std::min(room, B - done);
+            if (!queueExamples_(dX + (std::size_t)done * n, count, nRows, nCols, lambdas ? lambdas + done : nullptr)) return false;
+            done += count;
+        }
+    }
+    return true;
+}
+
+void Wavenet::clear() {
+    scaleMomentum_(0.);
+    clearFilterLog();
+    clearCostLog();
+    if (m_session && m_session->ctx) {
+        wn_set_momentum(m_session->ctx, m_momentum.memptr(), (int)m_momentum.n_elem);
+        wn_clear_logs(m_session->ctx);
+    }
+}
+
+/// High-level cost method(s).
+double Wavenet::cost(const Col& y) {
+    const double S = SparseTerm(y);
+    const double R = lambda() * RegTerm(m_filter, m_wavelet);
+    return S + R;
+}
+
+double Wavenet::cost(const Mat& Y) {
+    const double S = SparseTerm(Y);
+    const double R = lambda() * RegTerm(m_filter, m_wavelet);
+    return S + R;
+}
+
+std::vector<Mat> Wavenet::costMap(const std::vector<Mat>& X, const double& range, const unsigned& Ndiv) {
+    std::vector<Mat> costs(3);
+    for (Mat& M : costs) M.zeros(Ndiv, Ndiv);
+    const unsigned nExample = (unsigned)X.size();
+    if (!nExample) return costs;
+    const unsigned R = (unsigned)X[0].n_rows, C = (unsigned)X[0].n_cols;
+    const std::size_t n = (std::size_t)R * C;
+    DeviceSession& dev = device_();
+    std::vector<double> host((std::size_t)nExample * n), S(nExample);
+    for (unsigned e = 0; e < nExample; e++) std::memcpy(host.data() + e * n, X[e].memptr(), n * sizeof(double));
+    double* dX = dev.buf(DeviceSession::X, host.size());
+    double* dY = dev.buf(DeviceSession::Y, host.size());
+    double* dS = dev.buf(DeviceSession::S, nExample);
+    if (!dev.up(dX, host.data(), host.size())) return costs;
+    for (unsigned i = 0; i < Ndiv; i++) {
+        for (unsigned j = 0; j < Ndiv; j++) {
+            const double a1 = (2 * j / double(Ndiv - 1) - 1) * range;
+            const double a2 = (2 * i / double(Ndiv - 1) - 1) * range;
+            setFilter({a1, a2});
+            bool ok = dev.ok(wn_forward(dev.ctx, dX, (int)nExample, (int)R, (int)C, dY, nullptr, nullptr, nullptr)) &&
+                      dev.ok(wn_sparse_term(dev.ctx, dY, (int)nExample, (int)n, dS)) && dev.down(S.data(), dS, nExample);
+            if (!ok) return costs;
+            const double reg = lambda() * RegTerm(m_filter, m_wavelet);
+            for (unsigned e = 0; e < nExample; e++) {
+                costs[0](i, j) += S[e] + reg;
+                costs[1](i, j) += S[e];
+                costs[2](i, j) += reg;
+            }
+        }
+    }
+    for (Mat& M : costs) {
+        for (std::size_t k = 0; k < M.n_elem; k++) M(k) /= (double)nExample;
+    }
+    return costs;
+}
+
+/// Basis function method(s).
+Mat Wavenet::basisFunction1D(const unsigned& nRows, const unsigned& irow) {
+    if (!isRadix2(nRows)) {
+        WARNING("Cannot produce 1D basis function with length %d. Exiting.", nRows);
+        return Mat();
+    }
+    if (irow >= nRows) {
+        WARNING("Requested index (%d) is out of bounds with length %d. Exiting.", irow, nRows);
+        return Mat();
+    }
+    Mat Y(nRows, 1);
+    Y(irow, 0) = 1.;
+    return inverse_(Y);
+}
+
+Mat Wavenet::basisFunction2D(const unsigned& nRows, const unsigned& nCols, const unsigned& irow, const unsigned& icol) {
+    if (!isRadix2(nRows) || !isRadix2(nCols)) {
+        WARNING("Cannot produce 2D basis function for shape {%d, %d}. Exiting.", nRows, nCols);
+        return Mat();
+    }
+    if (irow >= nRows || icol >= nCols) {
+        WARNING("Requested indices (%d, %d) are out of bounds with shape {%d, %d}. Exiting.", irow, icol, nRows, nCols);
+        return Mat();
+    }
+    Mat Y(nRows, nCols);
+    Y(irow, icol) = 1.;
+    return inverse_(Y);
+}
+
+Mat Wavenet::basisFunction(const unsigned& nRows, const unsigned& nCols, const unsigned& irow, const unsigned& icol) {
+    if (nCols == 1) { assert(icol < 1); return basisFunction1D(nRows, irow); }
+    if (nRows == 1) { assert(irow < 1); return basisFunction1D(nCols, icol); }
+    return basisFunction2D(nRows, nCols, irow, icol);
+}
+
+/// Transform method(s).
+namespace {
+
+// Activations of one line from its pyramid P (P[2^i + k] = low-pass level i), its coefficient
+// vector y and the line itself.
+Activations1D_t lineActivations(const double* x, const double* P, const double* y, std::size_t n, std::size_t stride) {
+    const unsigned m = ilog2((unsigned)n);
+    Activations1D_t act(m + 1);
+    for (unsigned i = 0; i < m; i++) {
+        const std::size_t len = (std::size_t)1 << i;
+        act[i][0].zeros(len);
+        act[i][1].zeros(len);
+        for (std::size_t k = 0; k < len; k++) {
+            act[i][0](k) = P[(len + k) * stride];
+            act[i][1](k) = y[(len + k) * stride];
+        }
+    }
+    act[m][0].zeros(n);
+    act[m][1].zeros(n);
+    for (std::size_t k = 0; k < n; k++) act[m][0](k) = x[k * stride];
+    return act;
+}
+
+// The inverse of lineActivations for the arrays the backward kernels read.
+void scatterLine(const Activations1D_t& act, double* x, double* P, std::size_t n, std::size_t stride) {
+    const unsigned m = ilog2((unsigned)n);
+    P[0] = 0;
+    for (unsigned i = 0; i < m; i++) {
+        const std::size_t len = (std::size_t)1 << i;
+        for (std::size_t k = 0; k < len; k++) P[(len + k) * stride] = act[i][0](k);
+    }
+    for (std::size_t k = 0; k < n; k++) x[k * stride] = act[m][0](k);
+}
+
+}  // namespace
+
+Activations2D_t Wavenet::forward_(const Mat& X) {
+    Activations2D_t Activations(2);
+    const unsigned R = (unsigned)X.n_rows, C = (unsigned)X.n_cols;
+    if (!checkShape_(R, C)) return Activations;
+    DeviceSession& dev = device_();
+    const std::size_t n = (std::size_t)R * C;
+    double* dX = dev.buf(DeviceSession::X, n);
+    double* dY = dev.buf(DeviceSession::Y, n);
+    double* dPr = dev.buf(DeviceSession::PROW, n);
+    double* dY1 = dev.buf(DeviceSession::Y1, n);
+    double* dPc = dev.buf(DeviceSession::PCOL, n);
+    std::vector<double> Y(n), Pr(n), Y1(n), Pc(n);
+    bool ok = dev.up(dX, X.memptr(), n) && dev.ok(wn_forward(dev.ctx, dX, 1, (int)R, (int)C, dY, dPr, dY1, dPc)) &&
+              dev.down(Y.data(), dY, n) && dev.down(Pr.data(), dPr, n) && dev.down(Y1.data(), dY1, n) &&
+              dev.down(Pc.data(), dPc, n);
+    if (!ok) return Activations;
+    Activations[0].resize(R);
+    Activations[1].resize(C);
+    for (unsigned r = 0; r < R; r++) Activations[0][r] = lineActivations(X.memptr() + r, Pr.data() + r, Y1.data() + r, C, R);
+    for (unsigned c = 0; c < C; c++)
+        Activations[1][c] = lineActivations(Y1.data() + (std::size_t)c * R, Pc.data() + (std::size_t)c * R, Y.data() + (std::size_t)c * R, R, 1);
+    return Activations;
+}
+
+Activations1D_t Wavenet::forward_(const Col& x) {
+    Mat X(x.n_elem, 1, x.memptr());
+    Activations2D_t A = forward_(X);
+    if (A[1].empty()) return Activations1D_t();
+    return A[1][0];
+}
+
+Mat Wavenet::inverse_(const Mat& Y) {
+    const unsigned R = (unsigned)Y.n_rows, C = (unsigned)Y.n_cols;
+    Mat X(R, C);
+    if (!checkShape_(R, C)) return X;
+    DeviceSession& dev = device_();
+    const std::size_t n = (std::size_t)R * C;
+    double* dY = dev.buf(DeviceSession::Y, n);
+    double* dX = dev.buf(DeviceSession::X, n);
+    if (dev.up(dY, Y.memptr(), n) && dev.ok(wn_inverse(dev.ctx, dY, 1, (int)R, (int)C, dX))) dev.down(X.memptr(), dX, n);
+    return X;
+}
+
+Col Wavenet::inverse_(const Col& y) {
+    const Mat X = inverse_(Mat(y.n_elem, 1, y.memptr()));
+    return Col(X.n_elem, X.memptr());
+}
+
+Col Wavenet::backpropagate_(const Mat& Delta, Activations2D_t Activations) {
+    const unsigned R = (unsigned)Activations.at(0).size(), C = (unsigned)Activations.at(1).size();
+    const int N = (int)m_filter.n_elem;
+    Col gradient(N);
+    if (!checkShape_(R, C) || Delta.n_rows != R || Delta.n_cols != C) return gradient;
+    const std::size_t n = (std::size_t)R * C;
+    std::vector<double> X(n), Pr(n), Y1(n), Pc(n);
+    for (unsigned r = 0; r < R; r++) scatterLine(Activations[0][r], X.data() + r, Pr.data() + r, C, R);
+    for (unsigned c = 0; c < C; c++) scatterLine(Activations[1][c], Y1.data() + (std::size_t)c * R, Pc.data() + (std::size_t)c * R, R, 1);
+    DeviceSession& dev = device_();
+    double* dD = dev.buf(DeviceSession::DELTA, n);
+    double* dX = dev.buf(DeviceSession::X, n);
+    double* dPr = dev.buf(DeviceSession::PROW, n);
+    double* dY1 = dev.buf(DeviceSession::Y1, n);
+    double* dPc = dev.buf(DeviceSession::PCOL, n);
+    double* dG = dev.buf(DeviceSession::GRAD, N);
+    bool ok = dev.up(dD, Delta.memptr(), n) && dev.up(dX, X.data(), n) && dev.up(dPr, Pr.data(), n) &&
+              dev.up(dY1, Y1.data(), n) && dev.up(dPc, Pc.data(), n) &&
+              dev.ok(wn_backprop(dev.ctx, dD, dX, dPr, dY1, dPc, 1, (int)R, (int)C, dG, nullptr));
+    if (ok) dev.down(gradient.memptr(), dG, N);
+    return gradient;
+}
+
+std::vector<Col> Wavenet::backpropagate_(const Col& delta, Activations1D_t activations) {
+    const unsigned n = (unsigned)delta.n_elem;
+    const int N = (int)m_filter.n_elem;
+    std::vector<Col> output(2);
+    output[0].zeros(N);
+    output[1].zeros(n);
+    if (!checkShape_(n, 1) || activations.size() != ilog2(n) + 1) return output;
+    std::vector<double> x(n), P(n), zeros(n, 0.0);
+    scatterLine(activations, x.data(), P.data(), n, 1);
+    DeviceSession& dev = device_();
+    double* dD = dev.buf(DeviceSession::DELTA, n);
+    double* dX = dev.buf(DeviceSession::X, n);   // column stage input = the signal itself
+    double* dPr = dev.buf(DeviceSession::PROW, n);
+    double* dPc = dev.buf(DeviceSession::PCOL, n);
+    double* dG = dev.buf(DeviceSession::GRAD, N);
+    double* dIn = dev.buf(DeviceSession::Y, n);
+    bool ok = dev.up(dD, delta.memptr(), n) && dev.up(dX, x.data(), n) && dev.up(dPr, zeros.data(), n) &&
+              dev.up(dPc, P.data(), n) &&
+              dev.ok(wn_backprop(dev.ctx, dD, dX, dPr, dX, dPc, 1, (int)n, 1, dG, dIn));
+    if (ok) {
+        dev.down(output[0].memptr(), dG, N);
+        dev.down(output[1].memptr(), dIn, n);
+    }
+    return output;
+}
+
+/// Low-level learning method(s).
+double Wavenet::effectiveInertia_(unsigned steps) const {
+    return m_inertiaTimeScale > 0. ? m_inertia * (1. - std::exp(-float(steps) / m_inertiaTimeScale)) : m_inertia;
+}
+
+void Wavenet::flushBatchQueue_() {
+    if (!m_batchQueue.size()) return;
+    Col gradient(m_filter.n_elem);
+    for (std::size_t i = 0; i < m_batchQueue.size(); i++) gradient = gradient + m_batchQueue.at(i);
+    for (std::size_t k = 0; k < gradient.n_elem; k++) gradient(k) /= float(m_batchQueue.size());
+    this->update_(gradient);
+    m_costLog.back() /= float(m_batchQueue.size());
+    m_costLog.push_back(0);
+    m_batchQueue.clear();
+}
+
+void Wavenet::addMomentum_(const Col& gradient) {
+    if (m_momentum.n_elem > 0) m_momentum = m_momentum + gradient;
+    else m_momentum = gradient;
+}
+
+void Wavenet::scaleMomentum_(const double& factor) { m_momentum = m_momentum * factor; }
+
+void Wavenet::update_(const Col& gradient) {
+    const unsigned steps = (unsigned)m_costLog.size() - 1;
+    scaleMomentum_(effectiveInertia_(steps));
+    addMomentum_(gradient * (-m_alpha));
+    setFilter(m_filter + m_momentum);
+    if (m_session && m_session->ctx) wn_set_momentum(m_session->ctx, m_momentum.memptr(), (int)m_momentum.n_elem);
+}
+
+}  // namespace wavenet
