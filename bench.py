@@ -27,6 +27,8 @@ WORKLOADS = {
     # name: (R, C, per-GPU batch, default taps, generator)
     "2d64": (64, 64, 4096, 4, "calorimeter"),
     "1d1024": (1024, 1, 4096, 16, "bumps"),
+    "2d512": (512, 512, 256, 4, "calorimeter"),     # streamed path; per-GPU batch reduced from 2048 to keep host generation short
+    "1d1m": (1 << 20, 1, 8, 32, "bumps"),           # streamed path, 8 signals per GPU
 }
 
 
@@ -152,8 +154,7 @@ def main():
         kavg = float(np.mean(kernel_ms)) * 1e-3
         achieved = B * algorithmic_bytes(R, C) / kavg / 1e9
         out = {
-            "metric": "training examples/sec (fwd+backprop+update), 2D 64x64" if args.workload == "2d64"
-                      else "training examples/sec (fwd+backprop+update), 1D 1024",
+            "metric": f"training examples/sec (fwd+backprop+update), {'2D' if C > 1 else '1D'} {R}x{C}",
             "value": value, "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",

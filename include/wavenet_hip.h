@@ -40,7 +40,7 @@ enum {
     WN_ERR_ARG = 1,          /* null pointer, negative count                                   */
     WN_ERR_BAD_SHAPE = 2,    /* R or C not a power of two (src/GeneratorBase.cxx:15-49)        */
     WN_ERR_BAD_FILTER = 3,   /* empty or odd-length filter (src/Wavenet.cxx:11-19)             */
-    WN_ERR_UNSUPPORTED = 4,  /* shape or filter length outside what this build covers          */
+    WN_ERR_UNSUPPORTED = 4,  /* filter longer than WN_MAX_TAPS, example beyond 2^30 samples        */
     WN_ERR_HIP = 5,          /* a HIP runtime call failed                                       */
     WN_ERR_COMM = 6,         /* an RCCL call failed                                             */
     WN_ERR_NONFINITE = 7,    /* NaN/Inf in cost or gradient ("diverging solution",
@@ -49,7 +49,8 @@ enum {
 };
 
 #define WN_MAX_TAPS 32       /* longest filter the compiled kernels take */
-#define WN_MAX_FUSED 4096    /* largest R*C handled by the LDS-resident kernels */
+#define WN_MAX_FUSED 4096    /* largest R*C of the LDS-resident kernels; larger examples take the streamed
+                                path (one kernel per level, device workspace owned by the context) */
 
 typedef struct wn_context wn_context;
 

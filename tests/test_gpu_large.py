@@ -1,0 +1,129 @@
+"""The streamed path (R*C > 4096: level-by-level kernels, segmented radix sort) against the CPU oracle,
+including the full sizes of the 512x512 and 2^20-sample configurations."""
+import numpy as np
+import pytest
+
+import filters as F
+from gpu_util import dev_empty, from_dev, relerr, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    from wavenet_amd import Context
+    c = Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    yield c
+    torch.cuda.synchronize()
+    c.close()
+
+
+def filt_for(N, seed=0):
+    if N in (2, 4, 8, 16):
+        return F.perturbed(F.daubechies(N), 1e-2, seed)
+    return F.random_filter(N, seed)
+
+
+@pytest.mark.parametrize("R,C,N", [(128, 64, 4), (64, 128, 2), (8192, 1, 16), (1, 8192, 6), (256, 128, 32), (2, 4096, 8),
+                                   (512, 512, 4)])
+def test_forward_inverse_backprop(ctx, oracle, R, C, N):
+    import torch
+    B = 2
+    a = filt_for(N, 1)
+    rng = np.random.default_rng(R + C + N)
+    X = rng.random((B, R, C))
+    D = rng.standard_normal((B, R, C))
+    ctx.set_filter(a)
+    n = R * C
+    dX = to_dev(X)
+    dY, dPr, dY1, dPc, dXr = (dev_empty(B * n) for _ in range(5))
+    ctx.forward(dX, B, R, C, dY, dPr, dY1, dPc)
+    ctx.inverse(dY, B, R, C, dXr)
+    dG, dDin = dev_empty(B * N), dev_empty(B * n)
+    ctx.backprop(to_dev(D), dX, dPr, dY1, dPc, B, R, C, dG, dDin)
+    torch.cuda.synchronize()
+    Y, Pr, Y1, Pc, Xr = (from_dev(t, B, R, C) for t in (dY, dPr, dY1, dPc, dXr))
+    G = dG.cpu().numpy().reshape(B, N)
+    for e in range(B):
+        oPr, oY1, oPc, oY = oracle.band_forward_2d(a, X[e])
+        assert relerr(Y[e], oY) < 1e-11
+        assert relerr(Y1[e], oY1) < 1e-11
+        assert np.abs(Pr[e] - oPr).max() < 1e-11 * max(1.0, np.abs(oPr).max())
+        assert np.abs(Pc[e] - oPc).max() < 1e-11 * max(1.0, np.abs(oPc).max())
+        assert relerr(Xr[e], oracle.band_inverse_2d(a, oY)) < 1e-10
+        og = oracle.band_backprop_2d(a, D[e], X[e], oPr, oY1, oPc)
+        assert relerr(G[e], og) < 1e-10
+
+
+@pytest.mark.parametrize("n", [8192, 65536, 1 << 20])
+def test_sparse_term_and_deriv(ctx, oracle, n):
+    import torch
+    B = 3
+    rng = np.random.default_rng(n)
+    Y = rng.standard_normal((B, n))
+    Y[1, ::3] = 0.0
+    Y[2, :] = np.where(rng.random(n) < 0.5, 0.5, -0.5) * (1 + (np.arange(n) % 5))  # heavy ties
+    dY = torch.from_numpy(Y.reshape(-1)).cuda()
+    dD, dS = dev_empty(B * n), dev_empty(B)
+    ctx.sparse_term_deriv(dY, B, n, dD, dS)
+    torch.cuda.synchronize()
+    D = dD.cpu().numpy().reshape(B, n)
+    S = dS.cpu().numpy()
+    for e in range(B):
+        assert S[e] == pytest.approx(oracle.sparse_term(Y[e]), rel=1e-11)
+        assert relerr(D[e], oracle.sparse_term_deriv(Y[e])) < 1e-10
+    onehot = np.zeros((1, n))
+    onehot[0, n // 3] = 2.0
+    ctx.sparse_term(torch.from_numpy(onehot.reshape(-1)).cuda(), 1, n, dS)
+    assert dS.cpu().numpy()[0] == pytest.approx(1.0 / n, rel=1e-12)
+
+
+@pytest.mark.parametrize("R,C,N,B", [(128, 64, 4, 5), (8192, 1, 16, 3), (512, 512, 4, 2), (512, 512, 16, 2),
+                                     (1 << 20, 1, 32, 2)])
+def test_train_batch(ctx, oracle, R, C, N, B):
+    """Batch sums and per-example values of the full step; 512x512 and 2^20 x 1 are the full sizes of the
+    data-parallel configurations."""
+    import torch
+    from wavenet_amd import generators as G
+    a = filt_for(N, 2)
+    X = G.calorimeter(B, R, C, seed=3) if C > 1 else G.bumps(B, R, seed=3)
+    ctx.set_filter(a)
+    dG, dS = dev_empty(B * N), dev_empty(B)
+    ctx.train_batch(to_dev(X), B, R, C, dG, dS)
+    sums = ctx.sums()
+    Gd = dG.cpu().numpy().reshape(B, N)
+    Sd = dS.cpu().numpy()
+    og, os_, bad = oracle.band_train_batch(a, X)
+    assert bad == 0 and sums[N + 1] == 0
+    assert relerr(sums[:N], og) < 1e-9
+    assert sums[N] == pytest.approx(os_, rel=1e-11)
+    ge, se, _ = oracle.band_train_batch(a, X[:1])
+    assert relerr(Gd[0], ge) < 1e-9
+    assert Sd[0] == pytest.approx(se, rel=1e-11)
+    # without per-example outputs the sums are the same
+    ctx.train_batch(to_dev(X), B, R, C)
+    assert np.array_equal(ctx.sums(), sums)
+
+
+def test_full_size_properties_512(ctx):
+    """Size-independent properties at 512x512: perfect reconstruction for an orthonormal filter, linearity of
+    the forward transform, and energy conservation (Parseval) of the coefficients."""
+    import torch
+    from wavenet_amd import generators as G
+    R = C = 512
+    B = 4
+    X = G.calorimeter(B, R, C, seed=9)
+    ctx.set_filter(F.daubechies(8))
+    n = R * C
+    dX = to_dev(X)
+    dY, dXr, dY2 = dev_empty(B * n), dev_empty(B * n), dev_empty(B * n)
+    ctx.forward(dX, B, R, C, dY)
+    ctx.inverse(dY, B, R, C, dXr)
+    ctx.forward(2.5 * dX, B, R, C, dY2)
+    torch.cuda.synchronize()
+    assert torch.allclose(dXr, dX, rtol=0, atol=1e-9)
+    assert torch.allclose(dY2, 2.5 * dY, rtol=1e-12, atol=1e-12)
+    ex = (dX.view(B, n) ** 2).sum(dim=1)
+    ey = (dY.view(B, n) ** 2).sum(dim=1)
+    assert torch.allclose(ex, ey, rtol=1e-9)

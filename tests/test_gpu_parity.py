@@ -238,6 +238,9 @@ def test_error_codes(ctx):
     with pytest.raises(capi.WavenetError) as e:
         ctx.set_filter(np.ones(34))
     assert e.value.status == capi.WN_ERR_UNSUPPORTED
+    with pytest.raises(capi.WavenetError) as e:
+        ctx.sparse_term(d, 1, 48, d)          # the sort kernels take powers of two
+    assert e.value.status == capi.WN_ERR_BAD_SHAPE
     ctx.set_filter(F.HAAR)
     ctx.train_batch(d, 0, 8, 8)  # empty batch: sums are zero
     assert np.all(ctx.sums() == 0)

@@ -15,6 +15,7 @@
 
 #include "wavenet_hip.h"
 #include "wn_costfn.h"
+#include "wn_internal.h"
 #include "wn_kernels.h"
 
 // kernel tables, one translation unit per compiled tap count (wn_fused_np.hip)
@@ -33,48 +34,11 @@ struct SizeClass { int T, Q, NS; };
 const SizeClass kSizeClasses[5] = {{64, 1, 128}, {64, 3, 512}, {128, 3, 1024}, {256, 3, 2048}, {512, 3, 4096}};
 const int kLogCap = 16384;
 
-thread_local std::string g_error;  // for the entry points that take no context
-
 }  // namespace
-
-struct wn_context {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int numCU = 0;
-    wn::FilterDev* dfilt = nullptr;
-    bool has_filter = false;
-    int N = 0, NP = 0;
-    double* partial = nullptr;
-    int partial_blocks = 0;
-    double* sums = nullptr;
-    double* own_sums = nullptr;
-    std::vector<hipEvent_t> prof_begin, prof_end;
-    int prof_used = 0;
-    double* log_filters = nullptr;
-    double* log_costs = nullptr;
-    void* nccl_lib = nullptr;
-    void* comm = nullptr;
-    int nranks = 1;
-    std::string err;
-    std::map<const void*, size_t> lds_configured;
-    std::map<std::pair<const void*, size_t>, int> occupancy;
-};
 
 namespace {
 
-int fail(wn_context* ctx, int code, const std::string& msg) {
-    if (ctx) ctx->err = msg;
-    g_error = msg;
-    return code;
-}
-
-#define WN_HIP(ctx, call)                                                                      \
-    do {                                                                                       \
-        hipError_t e_ = (call);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            return fail(ctx, WN_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
-    } while (0)
+using wn::fail;
 
 int ilog2_exact(int v) {  // -1 unless v is a power of two >= 1
     if (v < 1 || (v & (v - 1))) return -1;
@@ -119,10 +83,8 @@ int check_shape(wn_context* ctx, int B, int R, int C, bool need_filter, int* lgR
     if (*lgR < 0 || *lgC < 0)
         return fail(ctx, WN_ERR_BAD_SHAPE, "shape {" + std::to_string(R) + ", " + std::to_string(C) + "} is not radix 2");
     if (need_filter && !ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
-    *sc = size_class((long long)R * C);
-    if (*sc < 0)
-        return fail(ctx, WN_ERR_UNSUPPORTED, "R*C = " + std::to_string((long long)R * C) + " exceeds " +
-                                                  std::to_string(WN_MAX_FUSED) + " (LDS-resident kernels)");
+    *sc = size_class((long long)R * C);  // -1: beyond the LDS-resident kernels, streamed path
+    if (*lgR + *lgC > 30) return fail(ctx, WN_ERR_UNSUPPORTED, "more than 2^30 samples per example");
     return WN_OK;
 }
 
@@ -240,7 +202,7 @@ const char* wn_status_string(int status) {
     return "unknown status";
 }
 
-const char* wn_last_error(const wn_context* ctx) { return ctx ? ctx->err.c_str() : g_error.c_str(); }
+const char* wn_last_error(const wn_context* ctx) { return ctx ? ctx->err.c_str() : wn::global_error().c_str(); }
 
 int wn_create(int device, wn_context** out) {
     if (!out) return WN_ERR_ARG;
@@ -249,14 +211,14 @@ int wn_create(int device, wn_context** out) {
     ctx->device = device;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) {
-        g_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        wn::global_error() = std::string("hipSetDevice: ") + hipGetErrorString(e);
         delete ctx;
         return WN_ERR_HIP;
     }
     hipDeviceProp_t prop;
     e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) {
-        g_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        wn::global_error() = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
         delete ctx;
         return WN_ERR_HIP;
     }
@@ -265,7 +227,7 @@ int wn_create(int device, wn_context** out) {
     auto alloc = [&](void** p, size_t bytes) {
         hipError_t ee = hipMalloc(p, bytes);
         if (ee == hipSuccess) ee = hipMemset(*p, 0, bytes);
-        if (ee != hipSuccess) { g_error = std::string("hipMalloc: ") + hipGetErrorString(ee); rc = WN_ERR_HIP; }
+        if (ee != hipSuccess) { wn::global_error() = std::string("hipMalloc: ") + hipGetErrorString(ee); rc = WN_ERR_HIP; }
     };
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) rc = WN_ERR_HIP;
     ctx->own_stream = true;
@@ -292,6 +254,7 @@ int wn_destroy(wn_context* ctx) {
     (void)hipFree(ctx->dfilt);
     (void)hipFree(ctx->partial);
     (void)hipFree(ctx->own_sums);
+    (void)hipFree(ctx->workspace);
     for (hipEvent_t ev : ctx->prof_begin) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->prof_end) (void)hipEventDestroy(ev);
     (void)hipFree(ctx->log_filters);
@@ -435,6 +398,7 @@ int wn_forward(wn_context* ctx, const double* X, int B, int R, int C, double* Y,
     if (rc) return rc;
     if (B == 0) return WN_OK;
     if (!X) return fail(ctx, WN_ERR_ARG, "null input");
+    if (sc < 0) return wn::large_forward(ctx, X, B, lgR, lgC, Y, Prow, Y1, Pcol);
     const SizeClass& S = kSizeClasses[sc];
     wn::FusedArgs A;
     memset(&A, 0, sizeof(A));
@@ -450,6 +414,7 @@ int wn_inverse(wn_context* ctx, const double* Y, int B, int R, int C, double* X)
     if (rc) return rc;
     if (B == 0) return WN_OK;
     if (!Y || !X) return fail(ctx, WN_ERR_ARG, "null pointer");
+    if (sc < 0) return wn::large_inverse(ctx, Y, B, lgR, lgC, X);
     const SizeClass& S = kSizeClasses[sc];
     wn::FusedArgs A;
     memset(&A, 0, sizeof(A));
@@ -466,6 +431,7 @@ int wn_backprop(wn_context* ctx, const double* Delta, const double* X, const dou
     if (rc) return rc;
     if (B == 0) return WN_OK;
     if (!Delta || !X || !Prow || !Y1 || !Pcol || !grad) return fail(ctx, WN_ERR_ARG, "null pointer");
+    if (sc < 0) return wn::large_backprop(ctx, Delta, X, Prow, Y1, Pcol, B, lgR, lgC, grad, din);
     const SizeClass& S = kSizeClasses[sc];
     wn::FusedArgs A;
     memset(&A, 0, sizeof(A));
@@ -484,9 +450,9 @@ int wn_sparse_term_deriv(wn_context* ctx, const double* Y, int B, int n, double*
     int lgn = ilog2_exact(n);
     if (lgn < 0) return fail(ctx, WN_ERR_BAD_SHAPE, "number of coefficients is not radix 2");
     const int sc = size_class(n);
-    if (sc < 0) return fail(ctx, WN_ERR_UNSUPPORTED, "n exceeds the LDS-resident kernels");
     if (B == 0) return WN_OK;
     if (!Y) return fail(ctx, WN_ERR_ARG, "null input");
+    if (sc < 0) return wn::large_sparse(ctx, Y, B, n, Delta, Sout);
     const SizeClass& S = kSizeClasses[sc];
     wn::FusedArgs A;
     memset(&A, 0, sizeof(A));
@@ -524,7 +490,8 @@ int wn_train_batch(wn_context* ctx, const double* X, int B, int R, int C, double
     int rc = check_shape(ctx, B, R, C, true, &lgR, &lgC, &sc);
     if (rc) return rc;
     if (B > 0 && !X) return fail(ctx, WN_ERR_ARG, "null input");
-    const SizeClass& S = kSizeClasses[sc];
+    if (sc < 0 && B > 0) return wn::large_train(ctx, X, B, lgR, lgC, grad, Sout);
+    const SizeClass& S = kSizeClasses[sc < 0 ? 0 : sc];
     wn::FusedArgs A;
     memset(&A, 0, sizeof(A));
     A.B = B; A.lgR = lgR; A.lgC = lgC; A.filt = ctx->dfilt;
@@ -659,12 +626,12 @@ int wn_clear_logs(wn_context* ctx) {
 int wn_comm_unique_id(void* id128) {
     if (!id128) return WN_ERR_ARG;
     void* lib = open_rccl();
-    if (!lib) { g_error = std::string("dlopen librccl: ") + dlerror(); return WN_ERR_COMM; }
+    if (!lib) { wn::global_error() = std::string("dlopen librccl: ") + dlerror(); return WN_ERR_COMM; }
     auto f = (fn_ncclGetUniqueId)dlsym(lib, "ncclGetUniqueId");
-    if (!f) { g_error = "ncclGetUniqueId not found"; return WN_ERR_COMM; }
+    if (!f) { wn::global_error() = "ncclGetUniqueId not found"; return WN_ERR_COMM; }
     NcclId id;
     const int r = f(&id);
-    if (r != 0) { g_error = "ncclGetUniqueId failed: " + std::to_string(r); return WN_ERR_COMM; }
+    if (r != 0) { wn::global_error() = "ncclGetUniqueId failed: " + std::to_string(r); return WN_ERR_COMM; }
     memcpy(id128, &id, sizeof(id));
     return WN_OK;
 }

@@ -1,0 +1,72 @@
+// Shared between the translation units of libwavenet_hip.so: the context behind the opaque
+// wn_context handle, error plumbing, and the entry points of the streamed (large-shape) path.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "wavenet_hip.h"
+#include "wn_device.h"
+
+struct wn_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int numCU = 0;
+    wn::FilterDev* dfilt = nullptr;
+    bool has_filter = false;
+    int N = 0, NP = 0;
+    double* partial = nullptr;
+    int partial_blocks = 0;
+    double* sums = nullptr;
+    double* own_sums = nullptr;
+    std::vector<hipEvent_t> prof_begin, prof_end;
+    int prof_used = 0;
+    double* log_filters = nullptr;
+    double* log_costs = nullptr;
+    void* nccl_lib = nullptr;
+    void* comm = nullptr;
+    int nranks = 1;
+    std::string err;
+    std::map<const void*, size_t> lds_configured;
+    std::map<std::pair<const void*, size_t>, int> occupancy;
+    // streamed path: one grow-only device workspace
+    void* workspace = nullptr;
+    size_t workspace_bytes = 0;
+};
+
+namespace wn {
+
+inline std::string& global_error() {
+    static thread_local std::string e;  // for the entry points that take no context
+    return e;
+}
+
+inline int fail(wn_context* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    global_error() = msg;
+    return code;
+}
+
+// Streamed path for examples beyond the LDS-resident limit (R*C > WN_MAX_FUSED): every level of the
+// cascade is one kernel over the whole batch chunk, intermediates live in a device workspace.
+int large_forward(wn_context* ctx, const double* X, int B, int lgR, int lgC, double* Y, double* Prow, double* Y1, double* Pcol);
+int large_inverse(wn_context* ctx, const double* Y, int B, int lgR, int lgC, double* X);
+int large_backprop(wn_context* ctx, const double* Delta, const double* X, const double* Prow, const double* Y1,
+                   const double* Pcol, int B, int lgR, int lgC, double* grad, double* din);
+int large_sparse(wn_context* ctx, const double* Y, int B, long long n, double* Delta, double* S);
+// Leaves the N + 2 sums in ctx->sums like the fused path.
+int large_train(wn_context* ctx, const double* X, int B, int lgR, int lgC, double* grad, double* S);
+
+}  // namespace wn
+
+#define WN_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return wn::fail(ctx, WN_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));   \
+    } while (0)

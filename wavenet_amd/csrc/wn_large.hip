@@ -1,0 +1,509 @@
+// Streamed path for examples that do not fit the LDS-resident kernels (R*C > 4096), e.g. 512x512
+// images and 2^20-sample signals.  Every level of the cascade is one kernel over a chunk of the
+// batch; pyramids, coefficients and errors live in a device workspace (288 GB of HBM make that
+// cheap), the Gini ranks come from a segmented radix sort (stable, so equal magnitudes keep
+// ascending index order), and all reductions are two-stage and ordered (no atomics).
+//
+// Reference stages: forward_ (src/Wavenet.cxx:404-445, 562-622), SparseTerm(Deriv)
+// (src/CostFunctions.cxx:6-117), backpropagate_ (src/Wavenet.cxx:474-556, 665-711).
+#include <cstring>
+
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+
+#include <algorithm>
+
+#include "wn_internal.h"
+
+namespace wn {
+namespace {
+
+constexpr int BT = 256;        // threads per workgroup
+constexpr int GXMAX = 64;      // workgroups per example in the reducing kernels
+
+struct Geom {                   // lines of one pass inside an example of n doubles
+    int es, ls, lgNL, lgLen;
+    int lanesOnLines;
+};
+
+__device__ __forceinline__ void decode(int w, int lgNL, int lgInner, int lanesOnLines, int& line, int& k) {
+    if (lanesOnLines) { line = w & ((1 << lgNL) - 1); k = w >> lgNL; }
+    else              { k = w & ((1 << lgInner) - 1); line = w >> lgInner; }
+}
+
+// lo[k] = sum_j a[j] in[(N/2 + 2k - j) mod len], hi[k] with b; one level, whole chunk (grid.y = example).
+template <int NP>
+__global__ __launch_bounds__(BT) void kb_fwd_level(const double* __restrict__ in, double* __restrict__ lo,
+                                                   double* __restrict__ hi, size_t xs, Geom g, int lgHalf,
+                                                   const FilterDev* filt) {
+    double a[NP], b[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    const size_t off = (size_t)blockIdx.y * xs;
+    const int W = 1 << (g.lgNL + lgHalf), lmask = (2 << lgHalf) - 1;
+    for (int w = blockIdx.x * BT + threadIdx.x; w < W; w += gridDim.x * BT) {
+        int line, k;
+        decode(w, g.lgNL, lgHalf, g.lanesOnLines, line, k);
+        const double* src = in + off + (size_t)line * g.ls;
+        const int base = 2 * k + NP / 2;
+        double sl = 0, sh = 0;
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            const double v = src[(size_t)((base - j) & lmask) * g.es];
+            sl = __builtin_fma(a[j], v, sl);
+            sh = __builtin_fma(b[j], v, sh);
+        }
+        lo[off + (size_t)line * g.ls + (size_t)k * g.es] = sl;
+        hi[off + (size_t)line * g.ls + (size_t)k * g.es] = sh;
+    }
+}
+
+// out[line][0] = P[line][1] (lo_0), P[line][0] = 0
+__global__ void kb_finish_pass(double* out, double* P, size_t xs, Geom g) {
+    const size_t off = (size_t)blockIdx.y * xs;
+    for (int line = blockIdx.x * BT + threadIdx.x; line < (1 << g.lgNL); line += gridDim.x * BT) {
+        out[off + (size_t)line * g.ls] = P[off + (size_t)line * g.ls + g.es];
+        P[off + (size_t)line * g.ls] = 0;
+    }
+}
+
+// Filter-gradient correlation of one level (see bwd_level in wn_device.h for the indexing).
+// partial[(example * GXMAX + workgroup) * 2NP + u] accumulates over the launches of one backward.
+template <int NP>
+__global__ __launch_bounds__(BT) void kb_grad_level(const double* __restrict__ lp, const double* __restrict__ hp,
+                                                    const double* __restrict__ act, size_t xs, Geom g, int lgLen,
+                                                    double* partial) {
+    __shared__ double red[(BT / 64) * 2 * NP];
+    double gL[NP], gH[NP];
+#pragma unroll
+    for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
+    const size_t off = (size_t)blockIdx.y * xs;
+    const int W = 1 << (g.lgNL + lgLen), amask = (2 << lgLen) - 1;
+    for (int w = blockIdx.x * BT + threadIdx.x; w < W; w += gridDim.x * BT) {
+        int line, r;
+        decode(w, g.lgNL, lgLen, g.lanesOnLines, line, r);
+        const size_t lo = off + (size_t)line * g.ls;
+        const double dl = lp[lo + (size_t)r * g.es];
+        const double dh = hp[lo + (size_t)r * g.es];
+        const int base = 2 * r + NP / 2;
+#pragma unroll
+        for (int u = 0; u < NP; u++) {
+            const double v = act[lo + (size_t)((base - u) & amask) * g.es];
+            gL[u] = __builtin_fma(dl, v, gL[u]);
+            gH[u] = __builtin_fma(dh, v, gH[u]);
+        }
+    }
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < NP; u++) {
+        const double sl = wave_sum(gL[u]), sh = wave_sum(gH[u]);
+        if ((tid & 63) == 0) { red[(tid >> 6) * 2 * NP + u] = sl; red[(tid >> 6) * 2 * NP + NP + u] = sh; }
+    }
+    __syncthreads();
+    if (tid < 2 * NP) {
+        double s = 0;
+#pragma unroll
+        for (int wv = 0; wv < BT / 64; wv++) s += red[wv * 2 * NP + tid];
+        partial[((size_t)blockIdx.y * GXMAX + blockIdx.x) * 2 * NP + tid] += s;
+    }
+}
+
+// out[c] = sum over (r, j) with (N/2 + 2r - j) mod 2len == c of a[j] lp[r] + b[j] hp[r]
+template <int NP>
+__global__ __launch_bounds__(BT) void kb_prop_level(const double* __restrict__ lp, const double* __restrict__ hp,
+                                                    double* __restrict__ out, size_t xs, Geom g, int lgLen,
+                                                    const FilterDev* filt) {
+    double a[NP], b[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    constexpr int S = NP / 2;
+    constexpr int JE = S & 1, JO = (S + 1) & 1;
+    constexpr int CE = (JE - S) / 2, CO = (1 + JO - S) / 2;
+    const size_t off = (size_t)blockIdx.y * xs;
+    const int W = 1 << (g.lgNL + lgLen), rmask = (1 << lgLen) - 1;
+    for (int w = blockIdx.x * BT + threadIdx.x; w < W; w += gridDim.x * BT) {
+        int line, p;
+        decode(w, g.lgNL, lgLen, g.lanesOnLines, line, p);
+        const size_t lo = off + (size_t)line * g.ls;
+        double se = 0, so = 0;
+#pragma unroll
+        for (int i = 0; i < NP / 2; i++) {
+            const size_t re = lo + (size_t)((p + i + CE) & rmask) * g.es;
+            const size_t ro = lo + (size_t)((p + i + CO) & rmask) * g.es;
+            se = __builtin_fma(a[JE + 2 * i], lp[re], se);
+            se = __builtin_fma(b[JE + 2 * i], hp[re], se);
+            so = __builtin_fma(a[JO + 2 * i], lp[ro], so);
+            so = __builtin_fma(b[JO + 2 * i], hp[ro], so);
+        }
+        out[lo + (size_t)(2 * p) * g.es] = se;
+        out[lo + (size_t)(2 * p + 1) * g.es] = so;
+    }
+}
+
+// Per-example gradient from the per-workgroup window sums: tap k collects gL[k] and (-1)^(N-1-k) gH[N-1-k].
+__global__ void kb_grad_finish(const double* partial, int NP, const FilterDev* filt, double* grad_e) {
+    const int ex = blockIdx.x, kp = threadIdx.x;
+    if (kp >= NP) return;
+    double gl = 0, gh = 0;
+    for (int bx = 0; bx < GXMAX; bx++) {
+        const double* p = partial + ((size_t)ex * GXMAX + bx) * 2 * NP;
+        gl += p[kp];
+        gh += p[NP + (NP - 1 - kp)];
+    }
+    const int k = kp - filt->d;
+    if (k >= 0 && k < filt->N) grad_e[(size_t)ex * filt->N + k] = filt->vL[kp] * gl + filt->sH[kp] * gh;
+}
+
+// sums[0..N) += sum_e grad_e, sums[N] += sum_e S_e, sums[N+1] += number of non-finite values; example order.
+__global__ void kb_batch_sums(const double* grad_e, const double* S_e, int B, int N, double* sums, int first) {
+    const int t = threadIdx.x;
+    if (t > N + 1) return;
+    double s = first ? 0.0 : sums[t];
+    if (t < N) {
+        for (int e = 0; e < B; e++) s += grad_e[(size_t)e * N + t];
+    } else if (t == N) {
+        for (int e = 0; e < B; e++) s += S_e[e];
+    } else {
+        for (int e = 0; e < B; e++) {
+            if (!isfinite(S_e[e])) s += 1;
+            for (int k = 0; k < N; k++) {
+                if (!isfinite(grad_e[(size_t)e * N + k])) s += 1;
+            }
+        }
+    }
+    sums[t] = s;
+}
+
+// ---- Gini --------------------------------------------------------------------------------------------
+__global__ void kb_abs_iota(const double* Y, double* keys, unsigned* idx, size_t total, unsigned nmask) {
+    for (size_t i = (size_t)blockIdx.x * BT + threadIdx.x; i < total; i += (size_t)gridDim.x * BT) {
+        keys[i] = __builtin_fabs(Y[i]);
+        idx[i] = (unsigned)i & nmask;
+    }
+}
+__global__ void kb_offsets(unsigned* off, int B, unsigned n) {
+    for (int i = blockIdx.x * BT + threadIdx.x; i <= B; i += gridDim.x * BT) off[i] = (unsigned)i * n;
+}
+// part[(example * GXMAX + workgroup) * 2 + {0,1}] = partial f and partial sum |c|
+__global__ __launch_bounds__(BT) void kb_gini_partial(const double* sorted, unsigned n, double* part) {
+    __shared__ double red[2 * (BT / 64)];
+    const double* s = sorted + (size_t)blockIdx.y * n;
+    double f = 0, a = 0;
+    for (unsigned p = blockIdx.x * BT + threadIdx.x; p < n; p += gridDim.x * BT) {
+        const double v = s[p];
+        f = __builtin_fma(2.0 * (double)(p + 1) - (double)n - 1.0, v, f);
+        a += v;
+    }
+    f = wave_sum(f);
+    a = wave_sum(a);
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0) { red[tid >> 6] = f; red[BT / 64 + (tid >> 6)] = a; }
+    __syncthreads();
+    if (tid < 2) {
+        double t = 0;
+        for (int wv = 0; wv < BT / 64; wv++) t += red[tid * (BT / 64) + wv];
+        part[((size_t)blockIdx.y * GXMAX + blockIdx.x) * 2 + tid] = t;
+    }
+}
+__global__ void kb_gini_finish(const double* part, int B, int gx, unsigned n, double* fg, double* S_e) {
+    const int e = blockIdx.x * BT + threadIdx.x;
+    if (e >= B) return;
+    double f = 0, a = 0;
+    for (int bx = 0; bx < gx; bx++) { f += part[((size_t)e * GXMAX + bx) * 2]; a += part[((size_t)e * GXMAX + bx) * 2 + 1]; }
+    const double g = (double)n * a;
+    fg[2 * e] = f;
+    fg[2 * e + 1] = g;
+    if (S_e) S_e[e] = 1.0 - f / g;
+}
+// delta_j = -((2 rank_j - n - 1) sign g - f n sign) / g^2, in place over the coefficients
+__global__ __launch_bounds__(BT) void kb_gini_delta(const unsigned* idx_sorted, const double* Yin, double* Dout,
+                                                    const double* fg, unsigned n) {
+    const size_t off = (size_t)blockIdx.y * n;
+    const double f = fg[2 * blockIdx.y], g = fg[2 * blockIdx.y + 1];
+    const double inv_g2 = 1.0 / (g * g);
+    for (unsigned p = blockIdx.x * BT + threadIdx.x; p < n; p += gridDim.x * BT) {
+        const unsigned j = idx_sorted[off + p];
+        const double sg = sign_ref(Yin[off + j]);
+        const double df = (2.0 * (double)(p + 1) - (double)n - 1.0) * sg;
+        Dout[off + j] = -(df * g - f * ((double)n * sg)) * inv_g2;
+    }
+}
+
+// ---- workspace ----------------------------------------------------------------------------------------
+struct Carver {
+    char* base;
+    size_t used = 0;
+    template <class T>
+    T* take(size_t count) {
+        used = (used + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + used) : nullptr;
+        used += count * sizeof(T);
+        return p;
+    }
+};
+
+int ensure_workspace(wn_context* ctx, size_t bytes) {
+    if (ctx->workspace_bytes >= bytes) return WN_OK;
+    WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->workspace) (void)hipFree(ctx->workspace);
+    ctx->workspace = nullptr;
+    ctx->workspace_bytes = 0;
+    WN_HIP(ctx, hipMalloc(&ctx->workspace, bytes));
+    ctx->workspace_bytes = bytes;
+    return WN_OK;
+}
+
+inline dim3 grid_for(int items, int B, int cap = 4096) {
+    int gx = (items + BT - 1) / BT;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    return dim3((unsigned)gx, (unsigned)B);
+}
+
+// ---- passes ----------------------------------------------------------------------------------------------
+template <int NP>
+int fwd_pass_big(wn_context* ctx, const double* in, double* P, double* out, int B, size_t n, Geom g) {
+    hipStream_t st = ctx->stream;
+    if (g.lgLen == 0) {
+        WN_HIP(ctx, hipMemcpyAsync(out, in, (size_t)B * n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        WN_HIP(ctx, hipMemsetAsync(P, 0, (size_t)B * n * sizeof(double), st));
+        return WN_OK;
+    }
+    for (int i = g.lgLen - 1; i >= 0; i--) {
+        const double* src = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i) * g.es;
+        hipLaunchKernelGGL(kb_fwd_level<NP>, grid_for(1 << (g.lgNL + i), B), dim3(BT), 0, st, src,
+                           P + (size_t)(1 << i) * g.es, out + (size_t)(1 << i) * g.es, n, g, i, ctx->dfilt);
+    }
+    hipLaunchKernelGGL(kb_finish_pass, grid_for(1 << g.lgNL, B), dim3(BT), 0, st, out, P, n, g);
+    WN_HIP(ctx, hipGetLastError());
+    return WN_OK;
+}
+
+// Backward over the lines of one pass.  coef: errors on the coefficients of these lines; in/P: the
+// activations; pingA/pingB: two scratch arrays (distinct from coef).  *result points at the array
+// holding the errors on the input afterwards.  partial may be null (inverse transform: no gradient).
+template <int NP>
+int bwd_pass_big(wn_context* ctx, const double* coef, const double* in, const double* P, double* pingA,
+                 double* pingB, int B, size_t n, Geom g, bool lastPropagate, double* partial, const double** result) {
+    hipStream_t st = ctx->stream;
+    const double* lp = coef;
+    double* dst = pingA;
+    for (int i = 0; i < g.lgLen; i++) {
+        const double* hp = coef + (size_t)(1 << i) * g.es;
+        if (partial) {
+            const double* act = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i) * g.es;
+            hipLaunchKernelGGL(kb_grad_level<NP>, grid_for(1 << (g.lgNL + i), B, GXMAX), dim3(BT), 0, st, lp, hp, act, n, g, i, partial);
+        }
+        if (i != g.lgLen - 1 || lastPropagate) {
+            hipLaunchKernelGGL(kb_prop_level<NP>, grid_for(1 << (g.lgNL + i), B), dim3(BT), 0, st, lp, hp, dst, n, g, i, ctx->dfilt);
+            lp = dst;
+            dst = (dst == pingA) ? pingB : pingA;
+        }
+    }
+    WN_HIP(ctx, hipGetLastError());
+    if (result) *result = lp;
+    return WN_OK;
+}
+
+int gini_big(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB,
+             unsigned* idxA, unsigned* idxB, unsigned* offsets, double* gpart, double* fg, double* S_e,
+             void* sort_tmp, size_t sort_tmp_bytes) {
+    hipStream_t st = ctx->stream;
+    const size_t total = (size_t)B * n;
+    hipLaunchKernelGGL(kb_abs_iota, dim3((unsigned)std::min<size_t>((total + BT - 1) / BT, 65536)), dim3(BT), 0, st, Y, keysA, idxA, total, (unsigned)(n - 1));
+    hipLaunchKernelGGL(kb_offsets, dim3((B + BT) / BT), dim3(BT), 0, st, offsets, B, (unsigned)n);
+    WN_HIP(ctx, rocprim::segmented_radix_sort_pairs(sort_tmp, sort_tmp_bytes, keysA, keysB, idxA, idxB, (unsigned)total,
+                                                    (unsigned)B, offsets, offsets + 1, 0, 64, st));
+    const int gx = (int)std::min<size_t>((n + BT - 1) / BT, GXMAX);
+    hipLaunchKernelGGL(kb_gini_partial, dim3(gx, B), dim3(BT), 0, st, keysB, (unsigned)n, gpart);
+    hipLaunchKernelGGL(kb_gini_finish, dim3((B + BT - 1) / BT), dim3(BT), 0, st, gpart, B, gx, (unsigned)n, fg, S_e);
+    if (D) hipLaunchKernelGGL(kb_gini_delta, grid_for((int)std::min<size_t>(n, 1u << 30), B), dim3(BT), 0, st, idxB, Y, D, fg, (unsigned)n);
+    WN_HIP(ctx, hipGetLastError());
+    return WN_OK;
+}
+
+size_t sort_temp_bytes(size_t total, int B) {
+    size_t bytes = 0;
+    (void)rocprim::segmented_radix_sort_pairs(nullptr, bytes, (double*)nullptr, (double*)nullptr, (unsigned*)nullptr,
+                                              (unsigned*)nullptr, (unsigned)total, (unsigned)B, (unsigned*)nullptr,
+                                              (unsigned*)nullptr, 0, 64, (hipStream_t)0);
+    return bytes;
+}
+
+struct Plan {
+    int Bc;                 // examples per chunk
+    size_t n;
+    double *Prow, *Y1, *Pcol, *YD, *A, *Bb, *gpart, *fg, *partial, *grad_e, *S_e;
+    unsigned *idxA, *idxB, *offsets;
+    void* sort_tmp;
+    size_t sort_tmp_bytes;
+};
+
+int make_plan(wn_context* ctx, int B, size_t n, int NP, int N, Plan* pl) {
+    const size_t cap = (size_t)32 << 30;  // bytes of workspace at most
+    const size_t per_example = n * (6 * sizeof(double) + 2 * sizeof(unsigned)) + GXMAX * (2 * NP + 2) * sizeof(double) + 64 * sizeof(double);
+    size_t Bc = std::max<size_t>(1, std::min<size_t>((size_t)B, cap / per_example));
+    Bc = std::min<size_t>(Bc, ((size_t)1 << 31) / n);  // rocPRIM counts keys in 32 bits
+    Bc = std::min<size_t>(Bc, 65535);                   // grid.y
+    if (Bc < 1) return fail(ctx, WN_ERR_UNSUPPORTED, "example too large for the streamed path");
+    pl->Bc = (int)Bc;
+    pl->n = n;
+    pl->sort_tmp_bytes = sort_temp_bytes(Bc * n, (int)Bc);
+    for (int pass = 0; pass < 2; pass++) {
+        Carver c{pass ? (char*)ctx->workspace : nullptr};
+        pl->Prow = c.take<double>(Bc * n);
+        pl->Y1 = c.take<double>(Bc * n);
+        pl->Pcol = c.take<double>(Bc * n);
+        pl->YD = c.take<double>(Bc * n);
+        pl->A = c.take<double>(Bc * n);
+        pl->Bb = c.take<double>(Bc * n);
+        pl->idxA = c.take<unsigned>(Bc * n);
+        pl->idxB = c.take<unsigned>(Bc * n);
+        pl->offsets = c.take<unsigned>(Bc + 1);
+        pl->gpart = c.take<double>(Bc * GXMAX * 2);
+        pl->fg = c.take<double>(Bc * 2);
+        pl->partial = c.take<double>(Bc * GXMAX * 2 * NP);
+        pl->grad_e = c.take<double>(Bc * N);
+        pl->S_e = c.take<double>(Bc);
+        pl->sort_tmp = c.take<char>(pl->sort_tmp_bytes);
+        if (!pass) {
+            const int rc = ensure_workspace(ctx, c.used + 256);
+            if (rc) return rc;
+        }
+    }
+    return WN_OK;
+}
+
+Geom row_geom(int lgR, int lgC) { return Geom{1 << lgR, 1, lgR, lgC, 1}; }
+Geom col_geom(int lgR, int lgC) { return Geom{1, 1 << lgR, lgC, lgR, 0}; }
+
+template <int NP>
+int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double* grad, double* S, bool forward_only,
+               double* Yout, double* ProwOut, double* Y1Out, double* PcolOut) {
+    const size_t n = (size_t)1 << (lgR + lgC);
+    const int N = ctx->N;
+    Plan pl;
+    int rc = make_plan(ctx, B, n, NP, N, &pl);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    const Geom rg = row_geom(lgR, lgC), cg = col_geom(lgR, lgC);
+    for (int e0 = 0; e0 < B; e0 += pl.Bc) {
+        const int Bc = std::min(pl.Bc, B - e0);
+        const double* Xc = X + (size_t)e0 * n;
+        double* Prow = ProwOut ? ProwOut + (size_t)e0 * n : pl.Prow;
+        double* Y1 = Y1Out ? Y1Out + (size_t)e0 * n : pl.Y1;
+        double* Pcol = PcolOut ? PcolOut + (size_t)e0 * n : pl.Pcol;
+        double* YD = Yout ? Yout + (size_t)e0 * n : pl.YD;
+        if ((rc = fwd_pass_big<NP>(ctx, Xc, Prow, Y1, Bc, n, rg))) return rc;
+        if ((rc = fwd_pass_big<NP>(ctx, Y1, Pcol, YD, Bc, n, cg))) return rc;
+        if (forward_only) continue;
+        double* S_e = S ? S + e0 : pl.S_e;
+        double* grad_e = grad ? grad + (size_t)e0 * N : pl.grad_e;
+        if ((rc = gini_big(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.offsets, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes))) return rc;
+        WN_HIP(ctx, hipMemsetAsync(pl.partial, 0, (size_t)Bc * GXMAX * 2 * NP * sizeof(double), st));
+        const double* D1 = nullptr;
+        if ((rc = bwd_pass_big<NP>(ctx, YD, Y1, Pcol, pl.A, pl.Bb, Bc, n, cg, lgC > 0, pl.partial, &D1))) return rc;
+        if (lgC > 0) {
+            // D1 sits in A or Bb (or is YD itself when the column pass had no level); scratch: the other one and Pcol
+            double* other = (D1 == pl.A) ? pl.Bb : pl.A;
+            if ((rc = bwd_pass_big<NP>(ctx, D1, Xc, Prow, other, Pcol, Bc, n, rg, false, pl.partial, nullptr))) return rc;
+        }
+        hipLaunchKernelGGL(kb_grad_finish, dim3(Bc), dim3(64), 0, st, pl.partial, NP, ctx->dfilt, grad_e);
+        hipLaunchKernelGGL(kb_batch_sums, dim3(1), dim3(64), 0, st, grad_e, S_e, Bc, N, ctx->sums, e0 == 0 ? 1 : 0);
+        WN_HIP(ctx, hipGetLastError());
+    }
+    return WN_OK;
+}
+
+template <int NP>
+int inverse_impl(wn_context* ctx, const double* Y, int B, int lgR, int lgC, double* Xout) {
+    const size_t n = (size_t)1 << (lgR + lgC);
+    Plan pl;
+    int rc = make_plan(ctx, B, n, NP, ctx->N, &pl);
+    if (rc) return rc;
+    const Geom rg = row_geom(lgR, lgC), cg = col_geom(lgR, lgC);
+    for (int e0 = 0; e0 < B; e0 += pl.Bc) {
+        const int Bc = std::min(pl.Bc, B - e0);
+        const double* Yc = Y + (size_t)e0 * n;
+        const double* mid = nullptr;
+        const double* fin = nullptr;
+        if ((rc = bwd_pass_big<NP>(ctx, Yc, nullptr, nullptr, pl.A, pl.Bb, Bc, n, cg, true, nullptr, &mid))) return rc;
+        double* s1 = (mid == pl.A) ? pl.Bb : pl.A;
+        if ((rc = bwd_pass_big<NP>(ctx, mid, nullptr, nullptr, s1, pl.Pcol, Bc, n, rg, true, nullptr, &fin))) return rc;
+        WN_HIP(ctx, hipMemcpyAsync(Xout + (size_t)e0 * n, fin, (size_t)Bc * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return WN_OK;
+}
+
+template <int NP>
+int backprop_impl(wn_context* ctx, const double* Delta, const double* X, const double* Prow, const double* Y1,
+                  const double* Pcol, int B, int lgR, int lgC, double* grad, double* din) {
+    const size_t n = (size_t)1 << (lgR + lgC);
+    const int N = ctx->N;
+    Plan pl;
+    int rc = make_plan(ctx, B, n, NP, N, &pl);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    const Geom rg = row_geom(lgR, lgC), cg = col_geom(lgR, lgC);
+    for (int e0 = 0; e0 < B; e0 += pl.Bc) {
+        const int Bc = std::min(pl.Bc, B - e0);
+        const size_t o = (size_t)e0 * n;
+        WN_HIP(ctx, hipMemsetAsync(pl.partial, 0, (size_t)Bc * GXMAX * 2 * NP * sizeof(double), st));
+        const double* D1 = nullptr;
+        if ((rc = bwd_pass_big<NP>(ctx, Delta + o, Y1 + o, Pcol + o, pl.A, pl.Bb, Bc, n, cg, true, pl.partial, &D1))) return rc;
+        if (din) WN_HIP(ctx, hipMemcpyAsync(din + o, D1, (size_t)Bc * n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        if (lgC > 0) {
+            double* other = (D1 == pl.A) ? pl.Bb : pl.A;
+            if ((rc = bwd_pass_big<NP>(ctx, D1, X + o, Prow + o, other, pl.Pcol, Bc, n, rg, false, pl.partial, nullptr))) return rc;
+        }
+        hipLaunchKernelGGL(kb_grad_finish, dim3(Bc), dim3(64), 0, st, pl.partial, NP, ctx->dfilt, grad + (size_t)e0 * N);
+        WN_HIP(ctx, hipGetLastError());
+    }
+    return WN_OK;
+}
+
+}  // namespace
+
+int large_train(wn_context* ctx, const double* X, int B, int lgR, int lgC, double* grad, double* S) {
+#define CALL(NPV) train_impl<NPV>(ctx, X, B, lgR, lgC, grad, S, false, nullptr, nullptr, nullptr, nullptr)
+    switch (ctx->NP) { case 2: return CALL(2); case 4: return CALL(4); case 8: return CALL(8); case 16: return CALL(16); case 32: return CALL(32); }
+#undef CALL
+    return fail(ctx, WN_ERR_UNSUPPORTED, "no kernels for this filter length");
+}
+
+int large_forward(wn_context* ctx, const double* X, int B, int lgR, int lgC, double* Y, double* Prow, double* Y1, double* Pcol) {
+#define CALL(NPV) train_impl<NPV>(ctx, X, B, lgR, lgC, nullptr, nullptr, true, Y, Prow, Y1, Pcol)
+    switch (ctx->NP) { case 2: return CALL(2); case 4: return CALL(4); case 8: return CALL(8); case 16: return CALL(16); case 32: return CALL(32); }
+#undef CALL
+    return fail(ctx, WN_ERR_UNSUPPORTED, "no kernels for this filter length");
+}
+
+int large_inverse(wn_context* ctx, const double* Y, int B, int lgR, int lgC, double* X) {
+#define CALL(NPV) inverse_impl<NPV>(ctx, Y, B, lgR, lgC, X)
+    switch (ctx->NP) { case 2: return CALL(2); case 4: return CALL(4); case 8: return CALL(8); case 16: return CALL(16); case 32: return CALL(32); }
+#undef CALL
+    return fail(ctx, WN_ERR_UNSUPPORTED, "no kernels for this filter length");
+}
+
+int large_backprop(wn_context* ctx, const double* Delta, const double* X, const double* Prow, const double* Y1,
+                   const double* Pcol, int B, int lgR, int lgC, double* grad, double* din) {
+#define CALL(NPV) backprop_impl<NPV>(ctx, Delta, X, Prow, Y1, Pcol, B, lgR, lgC, grad, din)
+    switch (ctx->NP) { case 2: return CALL(2); case 4: return CALL(4); case 8: return CALL(8); case 16: return CALL(16); case 32: return CALL(32); }
+#undef CALL
+    return fail(ctx, WN_ERR_UNSUPPORTED, "no kernels for this filter length");
+}
+
+int large_sparse(wn_context* ctx, const double* Y, int B, long long n, double* Delta, double* S) {
+    Plan pl;
+    int rc = make_plan(ctx, B, (size_t)n, 2, 2, &pl);
+    if (rc) return rc;
+    for (int e0 = 0; e0 < B; e0 += pl.Bc) {
+        const int Bc = std::min(pl.Bc, B - e0);
+        const size_t o = (size_t)e0 * n;
+        if ((rc = gini_big(ctx, Y + o, Delta ? Delta + o : nullptr, Bc, (size_t)n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.offsets,
+                           pl.gpart, pl.fg, S ? S + e0 : nullptr, pl.sort_tmp, pl.sort_tmp_bytes)))
+            return rc;
+    }
+    return WN_OK;
+}
+
+}  // namespace wn
