@@ -137,29 +137,66 @@ __device__ void write_padded_filter(wn::FilterDev* f, const double* a) {
     }
 }
 
-// Wavenet::flushBatchQueue_ / update_ / setFilter (src/Wavenet.cxx:717-765, 8-36), one thread.
-__global__ void k_update(wn::FilterDev* f, const double* sums, double Bf, double lambda_sum, double alpha,
-                         double inertia_eff, int wavelet, double* logF, double* logC, int cap) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Wavenet::flushBatchQueue_ / update_ / setFilter (src/Wavenet.cxx:717-765, 8-36), one wave: lane l
+// evaluates lag m = l - N/2 of the regularisation sums, lane i adds them up for tap i in the
+// reference's order.
+__global__ __launch_bounds__(64) void k_update(wn::FilterDev* f, const double* sums, double Bf, double lambda_sum,
+                                               double alpha, double inertia_eff, int wavelet, double* logF,
+                                               double* logC, int cap) {
+    __shared__ double a[wn::MAXTAPS], b[wn::MAXTAPS], prefA[wn::MAXTAPS + 1], prefB[wn::MAXTAPS + 1];
+    __shared__ float devA[wn::MAXTAPS + 1], devB[wn::MAXTAPS + 1];
+    __shared__ double anew[wn::MAXTAPS];
+    const int t = threadIdx.x;
     const int N = f->N;
-    double a[wn::MAXTAPS], regd[wn::MAXTAPS];
-    for (int k = 0; k < N; k++) a[k] = f->a_true[k];
-    wn::reg_term_deriv(a, N, wavelet != 0, regd);
-    const double reg = wn::reg_term(a, N, wavelet != 0);
-    for (int k = 0; k < N; k++) {
-        double gbar = sums[k] + lambda_sum * regd[k];
-        gbar /= Bf;                                   // gradient /= float(size)          :727
-        double p = f->momentum[k] * inertia_eff;      // scaleMomentum_                    :760
-        p += -alpha * gbar;                           // addMomentum_                      :761
-        f->momentum[k] = p;
-        a[k] = a[k] + p;                              // setFilter(m_filter + m_momentum)  :762
+    if (t < N) a[t] = f->a_true[t];
+    __syncthreads();
+    if (t < N) b[t] = wn::parity_sign(t) * a[N - t - 1];
+    __syncthreads();
+    if (t <= N) {
+        const int m = t - N / 2;
+        prefA[t] = wn::lag_prefactor(a, N, m);
+        devA[t] = wn::lag_deviation_sq_float(a, N, m);
+        prefB[t] = wn::lag_prefactor(b, N, m);
+        devB[t] = wn::lag_deviation_sq_float(b, N, m);
     }
-    const double cost = (sums[N] + lambda_sum * reg) / Bf;  // :227, :733
-    write_padded_filter(f, a);
-    const int idx = f->steps % cap;
-    for (int k = 0; k < wn::MAXTAPS; k++) logF[(size_t)idx * wn::MAXTAPS + k] = (k < N) ? a[k] : 0.0;
-    logC[idx] = cost;
-    f->steps = f->steps + 1;
+    __syncthreads();
+    const double suma = wn::sum_taps(a, N), sumb = wn::sum_taps(b, N);
+    if (t < N) {
+        double regd = 0;                                                            // RegTermDeriv, tap t
+        for (int l = 0; l <= N; l++) regd += prefA[l] * wn::lag_inner(a, N, t, l - N / 2);
+        if (wavelet) {
+            regd += 2 * (suma - 1.4142135623730951) * 1.0;
+            for (int l = 0; l <= N; l++) regd += prefB[l] * wn::lag_inner(a, N, t, l - N / 2);
+            regd += 2 * (sumb - 0) * wn::parity_sign(N - t - 1);
+        }
+        double gbar = sums[t] + lambda_sum * regd;
+        gbar /= Bf;                                   // gradient /= float(size)          :727
+        double p = f->momentum[t] * inertia_eff;      // scaleMomentum_                    :760
+        p += -alpha * gbar;                           // addMomentum_                      :761
+        f->momentum[t] = p;
+        anew[t] = a[t] + p;                           // setFilter(m_filter + m_momentum)  :762
+    }
+    __syncthreads();
+    if (t == 0) {
+        double reg = 0.;                                                            // RegTerm
+        float R2 = 0.f;
+        for (int l = 0; l <= N; l++) R2 = R2 + devA[l];
+        reg += R2;
+        if (wavelet) {
+            const double c1 = suma - 1.4142135623730951;
+            reg += c1 * c1;
+            float R3 = 0.f;
+            for (int l = 0; l <= N; l++) R3 = R3 + devB[l];
+            reg += R3;
+            reg += sumb * sumb;
+        }
+        reg = reg / 2.;
+        const int idx = f->steps % cap;
+        logC[idx] = (sums[N] + lambda_sum * reg) / Bf;                              // :227, :733
+        f->steps = f->steps + 1;
+        for (int k = 0; k < wn::MAXTAPS; k++) logF[(size_t)idx * wn::MAXTAPS + k] = (k < N) ? anew[k] : 0.0;
+        write_padded_filter(f, anew);
+    }
 }
 
 __global__ void k_reset_steps(wn::FilterDev* f) {

@@ -1,14 +1,15 @@
 // Streamed path for examples that do not fit the LDS-resident kernels (R*C > 4096), e.g. 512x512
 // images and 2^20-sample signals.  Every level of the cascade is one kernel over a chunk of the
 // batch; pyramids, coefficients and errors live in a device workspace (288 GB of HBM make that
-// cheap), the Gini ranks come from a segmented radix sort (stable, so equal magnitudes keep
-// ascending index order), and all reductions are two-stage and ordered (no atomics).
+// cheap), the Gini ranks come from two stable device-wide radix sorts per chunk (by magnitude, then
+// by example number, so equal magnitudes keep ascending index order), and all reductions are
+// two-stage and ordered (no atomics).
 //
 // Reference stages: forward_ (src/Wavenet.cxx:404-445, 562-622), SparseTerm(Deriv)
 // (src/CostFunctions.cxx:6-117), backpropagate_ (src/Wavenet.cxx:474-556, 665-711).
 #include <cstring>
 
-#include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
 
@@ -174,22 +175,23 @@ __global__ void kb_batch_sums(const double* grad_e, const double* S_e, int B, in
 }
 
 // ---- Gini --------------------------------------------------------------------------------------------
-__global__ void kb_abs_iota(const double* Y, double* keys, unsigned* idx, size_t total, unsigned nmask) {
+__global__ void kb_abs_iota(const double* Y, double* keys, unsigned* idx, size_t total) {
     for (size_t i = (size_t)blockIdx.x * BT + threadIdx.x; i < total; i += (size_t)gridDim.x * BT) {
         keys[i] = __builtin_fabs(Y[i]);
-        idx[i] = (unsigned)i & nmask;
+        idx[i] = (unsigned)i;  // position in the chunk: example * n + index
     }
 }
-__global__ void kb_offsets(unsigned* off, int B, unsigned n) {
-    for (int i = blockIdx.x * BT + threadIdx.x; i <= B; i += gridDim.x * BT) off[i] = (unsigned)i * n;
+__global__ void kb_segment_keys(const unsigned* idx, unsigned* seg, size_t total, int lgn) {
+    for (size_t i = (size_t)blockIdx.x * BT + threadIdx.x; i < total; i += (size_t)gridDim.x * BT) seg[i] = idx[i] >> lgn;
 }
-// part[(example * GXMAX + workgroup) * 2 + {0,1}] = partial f and partial sum |c|
-__global__ __launch_bounds__(BT) void kb_gini_partial(const double* sorted, unsigned n, double* part) {
+// part[(example * GXMAX + workgroup) * 2 + {0,1}] = partial f and partial sum |c|; pos[p] is the chunk
+// position of the p-th smallest magnitude of the example.
+__global__ __launch_bounds__(BT) void kb_gini_partial(const unsigned* pos, const double* Y, unsigned n, double* part) {
     __shared__ double red[2 * (BT / 64)];
-    const double* s = sorted + (size_t)blockIdx.y * n;
+    const unsigned* s = pos + (size_t)blockIdx.y * n;
     double f = 0, a = 0;
     for (unsigned p = blockIdx.x * BT + threadIdx.x; p < n; p += gridDim.x * BT) {
-        const double v = s[p];
+        const double v = __builtin_fabs(Y[s[p]]);
         f = __builtin_fma(2.0 * (double)(p + 1) - (double)n - 1.0, v, f);
         a += v;
     }
@@ -215,16 +217,16 @@ __global__ void kb_gini_finish(const double* part, int B, int gx, unsigned n, do
     if (S_e) S_e[e] = 1.0 - f / g;
 }
 // delta_j = -((2 rank_j - n - 1) sign g - f n sign) / g^2, in place over the coefficients
-__global__ __launch_bounds__(BT) void kb_gini_delta(const unsigned* idx_sorted, const double* Yin, double* Dout,
+__global__ __launch_bounds__(BT) void kb_gini_delta(const unsigned* pos, const double* Yin, double* Dout,
                                                     const double* fg, unsigned n) {
     const size_t off = (size_t)blockIdx.y * n;
     const double f = fg[2 * blockIdx.y], g = fg[2 * blockIdx.y + 1];
     const double inv_g2 = 1.0 / (g * g);
     for (unsigned p = blockIdx.x * BT + threadIdx.x; p < n; p += gridDim.x * BT) {
-        const unsigned j = idx_sorted[off + p];
-        const double sg = sign_ref(Yin[off + j]);
+        const unsigned j = pos[off + p];
+        const double sg = sign_ref(Yin[j]);
         const double df = (2.0 * (double)(p + 1) - (double)n - 1.0) * sg;
-        Dout[off + j] = -(df * g - f * ((double)n * sg)) * inv_g2;
+        Dout[j] = -(df * g - f * ((double)n * sg)) * inv_g2;
     }
 }
 
@@ -304,36 +306,51 @@ int bwd_pass_big(wn_context* ctx, const double* coef, const double* in, const do
     return WN_OK;
 }
 
+// Y, D: the chunk's coefficients / errors (D may alias Y or be null).
 int gini_big(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB,
-             unsigned* idxA, unsigned* idxB, unsigned* offsets, double* gpart, double* fg, double* S_e,
-             void* sort_tmp, size_t sort_tmp_bytes) {
+             unsigned* idxA, unsigned* idxB, double* gpart, double* fg, double* S_e, void* sort_tmp,
+             size_t sort_tmp_bytes) {
     hipStream_t st = ctx->stream;
     const size_t total = (size_t)B * n;
-    hipLaunchKernelGGL(kb_abs_iota, dim3((unsigned)std::min<size_t>((total + BT - 1) / BT, 65536)), dim3(BT), 0, st, Y, keysA, idxA, total, (unsigned)(n - 1));
-    hipLaunchKernelGGL(kb_offsets, dim3((B + BT) / BT), dim3(BT), 0, st, offsets, B, (unsigned)n);
-    WN_HIP(ctx, rocprim::segmented_radix_sort_pairs(sort_tmp, sort_tmp_bytes, keysA, keysB, idxA, idxB, (unsigned)total,
-                                                    (unsigned)B, offsets, offsets + 1, 0, 64, st));
+    const unsigned blocks = (unsigned)std::min<size_t>((total + BT - 1) / BT, 65536);
+    int lgn = 0;
+    while (((size_t)1 << lgn) < n) lgn++;
+    hipLaunchKernelGGL(kb_abs_iota, dim3(blocks), dim3(BT), 0, st, Y, keysA, idxA, total);
+    // by magnitude over the whole chunk (stable: equal magnitudes stay in position order) ...
+    WN_HIP(ctx, rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keysA, keysB, idxA, idxB, total, 0, 64, st));
+    const unsigned* pos = idxB;
+    if (B > 1) {
+        // ... then by example number, which groups the examples and keeps the magnitude order inside each
+        unsigned* segA = reinterpret_cast<unsigned*>(keysA);
+        unsigned* segB = reinterpret_cast<unsigned*>(keysB);
+        int bits = 1;
+        while ((1 << bits) < B) bits++;
+        hipLaunchKernelGGL(kb_segment_keys, dim3(blocks), dim3(BT), 0, st, idxB, segA, total, lgn);
+        WN_HIP(ctx, rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, segA, segB, idxB, idxA, total, 0, bits, st));
+        pos = idxA;
+    }
     const int gx = (int)std::min<size_t>((n + BT - 1) / BT, GXMAX);
-    hipLaunchKernelGGL(kb_gini_partial, dim3(gx, B), dim3(BT), 0, st, keysB, (unsigned)n, gpart);
+    hipLaunchKernelGGL(kb_gini_partial, dim3(gx, B), dim3(BT), 0, st, pos, Y, (unsigned)n, gpart);
     hipLaunchKernelGGL(kb_gini_finish, dim3((B + BT - 1) / BT), dim3(BT), 0, st, gpart, B, gx, (unsigned)n, fg, S_e);
-    if (D) hipLaunchKernelGGL(kb_gini_delta, grid_for((int)std::min<size_t>(n, 1u << 30), B), dim3(BT), 0, st, idxB, Y, D, fg, (unsigned)n);
+    if (D) hipLaunchKernelGGL(kb_gini_delta, grid_for((int)std::min<size_t>(n, 1u << 30), B), dim3(BT), 0, st, pos, Y, D, fg, (unsigned)n);
     WN_HIP(ctx, hipGetLastError());
     return WN_OK;
 }
 
-size_t sort_temp_bytes(size_t total, int B) {
-    size_t bytes = 0;
-    (void)rocprim::segmented_radix_sort_pairs(nullptr, bytes, (double*)nullptr, (double*)nullptr, (unsigned*)nullptr,
-                                              (unsigned*)nullptr, (unsigned)total, (unsigned)B, (unsigned*)nullptr,
-                                              (unsigned*)nullptr, 0, 64, (hipStream_t)0);
-    return bytes;
+size_t sort_temp_bytes(size_t total) {
+    size_t a = 0, b = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, a, (double*)nullptr, (double*)nullptr, (unsigned*)nullptr,
+                                    (unsigned*)nullptr, total, 0, 64, (hipStream_t)0);
+    (void)rocprim::radix_sort_pairs(nullptr, b, (unsigned*)nullptr, (unsigned*)nullptr, (unsigned*)nullptr,
+                                    (unsigned*)nullptr, total, 0, 32, (hipStream_t)0);
+    return std::max(a, b);
 }
 
 struct Plan {
     int Bc;                 // examples per chunk
     size_t n;
     double *Prow, *Y1, *Pcol, *YD, *A, *Bb, *gpart, *fg, *partial, *grad_e, *S_e;
-    unsigned *idxA, *idxB, *offsets;
+    unsigned *idxA, *idxB;
     void* sort_tmp;
     size_t sort_tmp_bytes;
 };
@@ -342,12 +359,12 @@ int make_plan(wn_context* ctx, int B, size_t n, int NP, int N, Plan* pl) {
     const size_t cap = (size_t)32 << 30;  // bytes of workspace at most
     const size_t per_example = n * (6 * sizeof(double) + 2 * sizeof(unsigned)) + GXMAX * (2 * NP + 2) * sizeof(double) + 64 * sizeof(double);
     size_t Bc = std::max<size_t>(1, std::min<size_t>((size_t)B, cap / per_example));
-    Bc = std::min<size_t>(Bc, ((size_t)1 << 31) / n);  // rocPRIM counts keys in 32 bits
+    Bc = std::min<size_t>(Bc, ((size_t)1 << 31) / n);  // chunk positions are kept in 32 bits
     Bc = std::min<size_t>(Bc, 65535);                   // grid.y
     if (Bc < 1) return fail(ctx, WN_ERR_UNSUPPORTED, "example too large for the streamed path");
     pl->Bc = (int)Bc;
     pl->n = n;
-    pl->sort_tmp_bytes = sort_temp_bytes(Bc * n, (int)Bc);
+    pl->sort_tmp_bytes = sort_temp_bytes(Bc * n);
     for (int pass = 0; pass < 2; pass++) {
         Carver c{pass ? (char*)ctx->workspace : nullptr};
         pl->Prow = c.take<double>(Bc * n);
@@ -358,7 +375,6 @@ int make_plan(wn_context* ctx, int B, size_t n, int NP, int N, Plan* pl) {
         pl->Bb = c.take<double>(Bc * n);
         pl->idxA = c.take<unsigned>(Bc * n);
         pl->idxB = c.take<unsigned>(Bc * n);
-        pl->offsets = c.take<unsigned>(Bc + 1);
         pl->gpart = c.take<double>(Bc * GXMAX * 2);
         pl->fg = c.take<double>(Bc * 2);
         pl->partial = c.take<double>(Bc * GXMAX * 2 * NP);
@@ -398,7 +414,7 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         if (forward_only) continue;
         double* S_e = S ? S + e0 : pl.S_e;
         double* grad_e = grad ? grad + (size_t)e0 * N : pl.grad_e;
-        if ((rc = gini_big(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.offsets, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes))) return rc;
+        if ((rc = gini_big(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes))) return rc;
         WN_HIP(ctx, hipMemsetAsync(pl.partial, 0, (size_t)Bc * GXMAX * 2 * NP * sizeof(double), st));
         const double* D1 = nullptr;
         if ((rc = bwd_pass_big<NP>(ctx, YD, Y1, Pcol, pl.A, pl.Bb, Bc, n, cg, lgC > 0, pl.partial, &D1))) return rc;
@@ -499,7 +515,7 @@ int large_sparse(wn_context* ctx, const double* Y, int B, long long n, double* D
     for (int e0 = 0; e0 < B; e0 += pl.Bc) {
         const int Bc = std::min(pl.Bc, B - e0);
         const size_t o = (size_t)e0 * n;
-        if ((rc = gini_big(ctx, Y + o, Delta ? Delta + o : nullptr, Bc, (size_t)n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.offsets,
+        if ((rc = gini_big(ctx, Y + o, Delta ? Delta + o : nullptr, Bc, (size_t)n, pl.A, pl.Bb, pl.idxA, pl.idxB,
                            pl.gpart, pl.fg, S ? S + e0 : nullptr, pl.sort_tmp, pl.sort_tmp_bytes)))
             return rc;
     }
