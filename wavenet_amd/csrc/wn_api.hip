@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -17,6 +18,7 @@
 #include "wn_costfn.h"
 #include "wn_internal.h"
 #include "wn_kernels.h"
+#include "wn_wave64.h"
 
 // kernel tables, one translation unit per compiled tap count (wn_fused_np.hip)
 extern "C" const void* wn_kernel_np2(int kind, int sc);
@@ -24,6 +26,7 @@ extern "C" const void* wn_kernel_np4(int kind, int sc);
 extern "C" const void* wn_kernel_np8(int kind, int sc);
 extern "C" const void* wn_kernel_np16(int kind, int sc);
 extern "C" const void* wn_kernel_np32(int kind, int sc);
+extern "C" const void* wn_kernel_wave64(int np);
 extern "C" const void* wn_kernel_sparse(int sc);
 
 namespace {
@@ -117,14 +120,16 @@ int launch(wn_context* ctx, const void* func, int T, size_t shmem, int B, wn::Fu
 
 // ---- small kernels ----------------------------------------------------------------------------
 
-// Sums the per-workgroup partials in workgroup order: sums[0..N) gradient, [N] sparse term,
-// [N+1] non-finite count.
-__global__ void k_reduce_partials(const double* partial, int nblocks, int N, double* sums) {
-    const int t = threadIdx.x;
+// Sums the partial-sum slots: sums[0..N) gradient, [N] sparse term, [N+1] non-finite count.  One
+// wave per quantity; lane l adds slots l, l + 64, ... in order, then the 64 lane sums are combined by
+// a butterfly -- a fixed order, so the result does not depend on timing.
+__global__ __launch_bounds__(64) void k_reduce_partials(const double* partial, int nslots, int N, double* sums) {
+    const int t = blockIdx.x, lane = threadIdx.x;
     if (t > N + 1) return;
     double s = 0;
-    for (int blk = 0; blk < nblocks; blk++) s += partial[(size_t)blk * wn::PSTRIDE + t];
-    sums[t] = s;
+    for (int slot = lane; slot < nslots; slot += 64) s += partial[(size_t)slot * wn::PSTRIDE + t];
+    s = wn::wave_sum(s);
+    if (lane == 0) sums[t] = s;
 }
 
 __device__ void write_padded_filter(wn::FilterDev* f, const double* a) {
@@ -269,6 +274,7 @@ int wn_create(int device, wn_context** out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) rc = WN_ERR_HIP;
     ctx->own_stream = true;
     ctx->partial_blocks = ctx->numCU * 16;
+    if (const char* w = getenv("WAVENET_HIP_WAVE64")) ctx->wave64 = (w[0] != '0');
     if (rc == WN_OK) alloc((void**)&ctx->dfilt, sizeof(wn::FilterDev));
     if (rc == WN_OK) alloc((void**)&ctx->partial, (size_t)ctx->partial_blocks * wn::PSTRIDE * sizeof(double));
     if (rc == WN_OK) alloc((void**)&ctx->own_sums, wn::PSTRIDE * sizeof(double));
@@ -535,10 +541,17 @@ int wn_train_batch(wn_context* ctx, const double* X, int B, int R, int C, double
     A.X = X; A.grad = grad; A.S = Sout; A.partial = ctx->partial;
     int grid = 0;
     if (B > 0) {
-        const size_t shmem = ((size_t)3 * R * C + S.NS + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double) + 16;
         const bool prof = ctx->prof_used < (int)ctx->prof_begin.size();
         if (prof) WN_HIP(ctx, hipEventRecord(ctx->prof_begin[ctx->prof_used], ctx->stream));
-        rc = launch(ctx, fused_kernel(ctx->NP, KIND_TRAIN, sc), S.T, shmem, B, A, &grid);
+        const void* wave64 = (lgR == 6 && lgC == 6 && ctx->wave64) ? wn_kernel_wave64(ctx->NP) : nullptr;
+        if (wave64) {
+            // one wave per example, four examples per workgroup; one partial-sum slot per wave
+            rc = launch(ctx, wave64, 256, (size_t)4 * wn::W64_TILE * sizeof(double), (B + 3) / 4, A, &grid);
+            grid *= 4;
+        } else {
+            const size_t shmem = ((size_t)3 * R * C + S.NS + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double) + 16;
+            rc = launch(ctx, fused_kernel(ctx->NP, KIND_TRAIN, sc), S.T, shmem, B, A, &grid);
+        }
         if (rc) return rc;
         if (prof) {
             WN_HIP(ctx, hipEventRecord(ctx->prof_end[ctx->prof_used], ctx->stream));
@@ -546,7 +559,7 @@ int wn_train_batch(wn_context* ctx, const double* X, int B, int R, int C, double
         }
         if (grid > ctx->partial_blocks) return fail(ctx, WN_ERR_STATE, "partial buffer too small");
     }
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(64), 0, ctx->stream, ctx->partial, grid, ctx->N, ctx->sums);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(ctx->N + 2), dim3(64), 0, ctx->stream, ctx->partial, grid, ctx->N, ctx->sums);
     WN_HIP(ctx, hipGetLastError());
     return WN_OK;
 }

@@ -22,6 +22,7 @@ struct wn_context {
     int N = 0, NP = 0;
     double* partial = nullptr;
     int partial_blocks = 0;
+    bool wave64 = true;  // 64x64 training on the one-wave-per-example kernel (WAVENET_HIP_WAVE64=0 turns it off)
     double* sums = nullptr;
     double* own_sums = nullptr;
     std::vector<hipEvent_t> prof_begin, prof_end;

@@ -1,0 +1,460 @@
+// Register-resident training kernel for 64x64 examples: ONE WAVE owns one example.
+//
+// Lane l holds row l (row stage) or column l (column stage) of the image in 64 registers, so the
+// whole filter cascade of a line -- forward, transposed (backward) and the filter-gradient
+// correlation -- is straight-line code on registers with compile-time indices: no LDS traffic, no
+// address arithmetic, no barrier.  LDS is used only for 64x64 transposes (row <-> column
+// orientation, and the lane <-> register exchange of the sort) in a per-wave 64x65 tile, and for
+// handing the ranks back.  Four such waves share a CU, each at its own pace.
+//
+// The Gini ranks come from a bitonic sort of 4096 keys, 64 per lane.  A key is |c| with its low 12
+// mantissa bits replaced by the element index: keys are unique, v_min_f64 / v_max_f64 carry the
+// index for free, and equal magnitudes come out in ascending index order.  Magnitudes that differ
+// only in those 12 bits come out as one group in index order; sparse inputs produce such groups all
+// the time (the same product rounded along two paths), so they are re-ranked in place by (low 12
+// bits, index) from small tables in LDS, which makes the order that of (exact magnitude, index).
+// Descending merge directions are realised by negating keys, so every compare-exchange is
+// min -> lower index.
+#pragma once
+
+#include "wn_kernels.h"
+
+namespace wn {
+
+constexpr int W64_TILE = 64 * 65;  // doubles of LDS per wave
+
+__device__ __forceinline__ void cmpx_asm(double& lo, double& hi) {
+    double mn, mx;
+    asm volatile("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(mn), "=&v"(mx) : "v"(lo), "v"(hi));
+    lo = mn;
+    hi = mx;
+}
+
+// ---- one line in registers ------------------------------------------------------------------------
+
+// Input of cascade level LG (2^(LG+1) samples): the line itself at the top, else pyramid level LG+1.
+template <int LG>
+__device__ __forceinline__ double w64_act(const double (&x)[64], const double (&p)[64], int idx) {
+    if constexpr (LG == 5) return x[idx];
+    else return p[(2 << LG) + idx];
+}
+
+// Forward cascade of a 64-sample line: y = coefficients, p[2^i + k] = low-pass level i (p[0] unused).
+template <int NP, int LG>
+__device__ __forceinline__ void w64_fwd_levels(const double (&x)[64], double (&p)[64], double (&y)[64],
+                                               const double (&a)[NP], const double (&b)[NP]) {
+    constexpr int half = 1 << LG, len = 2 * half;
+#pragma unroll
+    for (int k = 0; k < half; k++) {
+        double sl = 0, sh = 0;
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            const int idx = (2 * k + NP / 2 - j) & (len - 1);
+            const double v = w64_act<LG>(x, p, idx);
+            sl = __builtin_fma(a[j], v, sl);
+            sh = __builtin_fma(b[j], v, sh);
+        }
+        p[half + k] = sl;
+        y[half + k] = sh;
+    }
+    if constexpr (LG > 0) w64_fwd_levels<NP, LG - 1>(x, p, y, a, b);
+}
+
+template <int NP>
+__device__ __forceinline__ void w64_forward(const double (&x)[64], double (&p)[64], double (&y)[64],
+                                            const double (&a)[NP], const double (&b)[NP]) {
+    w64_fwd_levels<NP, 5>(x, p, y, a, b);
+    y[0] = p[1];
+    p[0] = 0;
+}
+
+// Low-pass pyramid only, levels 5..1 (what the backward pass reads).
+template <int NP, int LG>
+__device__ __forceinline__ void w64_pyramid_levels(const double (&x)[64], double (&p)[64], const double (&a)[NP]) {
+    constexpr int half = 1 << LG, len = 2 * half;
+#pragma unroll
+    for (int k = 0; k < half; k++) {
+        double sl = 0;
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            const int idx = (2 * k + NP / 2 - j) & (len - 1);
+            sl = __builtin_fma(a[j], w64_act<LG>(x, p, idx), sl);
+        }
+        p[half + k] = sl;
+    }
+    if constexpr (LG > 1) w64_pyramid_levels<NP, LG - 1>(x, p, a);
+}
+
+// Backward cascade of a line, levels LG = 0..5 (src/Wavenet.cxx:509-545): d in place.
+template <int NP, int LG, bool LASTPROP>
+__device__ __forceinline__ void w64_bwd_levels(double (&d)[64], const double (&x)[64], const double (&p)[64],
+                                               const double (&a)[NP], const double (&b)[NP],
+                                               double (&gL)[NP], double (&gH)[NP]) {
+    constexpr int len = 1 << LG, alen = 2 * len;
+#pragma unroll
+    for (int r = 0; r < len; r++) {
+        const double dl = d[r], dh = d[len + r];
+#pragma unroll
+        for (int u = 0; u < NP; u++) {
+            const int idx = (2 * r + NP / 2 - u) & (alen - 1);
+            const double v = w64_act<LG>(x, p, idx);
+            gL[u] = __builtin_fma(dl, v, gL[u]);
+            gH[u] = __builtin_fma(dh, v, gH[u]);
+        }
+    }
+    if constexpr (LG < 5 || LASTPROP) {
+        constexpr int S = NP / 2;
+        constexpr int JE = S & 1, JO = (S + 1) & 1;
+        constexpr int CE = (JE - S) / 2, CO = (1 + JO - S) / 2;
+        double nw[alen];
+#pragma unroll
+        for (int q = 0; q < len; q++) {
+            double se = 0, so = 0;
+#pragma unroll
+            for (int i = 0; i < NP / 2; i++) {
+                const int re = (q + i + CE) & (len - 1), ro = (q + i + CO) & (len - 1);
+                se = __builtin_fma(a[JE + 2 * i], d[re], se);
+                se = __builtin_fma(b[JE + 2 * i], d[len + re], se);
+                so = __builtin_fma(a[JO + 2 * i], d[ro], so);
+                so = __builtin_fma(b[JO + 2 * i], d[len + ro], so);
+            }
+            nw[2 * q] = se;
+            nw[2 * q + 1] = so;
+        }
+#pragma unroll
+        for (int c = 0; c < alen; c++) d[c] = nw[c];
+    }
+    if constexpr (LG < 5) w64_bwd_levels<NP, LG + 1, LASTPROP>(d, x, p, a, b, gL, gH);
+}
+
+// ---- 64x64 transpose through the wave's LDS tile -----------------------------------------------------
+// v[r] of lane l  ->  v[l] of lane r.  Row stride 65 doubles: conflict-free both ways.  A wave's LDS
+// operations execute in order, so no barrier is needed; the fence keeps the compiler from moving
+// the reads above the writes.
+__device__ __forceinline__ void w64_transpose(double (&v)[64], double* tile, int lane) {
+#pragma unroll
+    for (int r = 0; r < 64; r++) tile[lane * 65 + r] = v[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 64; r++) v[r] = tile[r * 65 + lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- sort ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void flip_sign(double& k, unsigned mask) {
+    k = __hiloint2double(__double2hiint(k) ^ (int)mask, __double2loint(k));
+}
+
+// compare-exchanges on register bit RB of all 64 keys
+template <int RB>
+__device__ __forceinline__ void w64_substage(double (&k)[64]) {
+#pragma unroll
+    for (int r = 0; r < 64; r++) {
+        if (!(r & (1 << RB))) cmpx_asm(k[r], k[r | (1 << RB)]);
+    }
+}
+template <int RB>
+__device__ __forceinline__ void w64_substages_down(double (&k)[64]) {
+    w64_substage<RB>(k);
+    if constexpr (RB > 0) w64_substages_down<RB - 1>(k);
+}
+
+// Merge step KK (blocks of 2^KK) of the bitonic sort.  Index e = lane * 64 + r in layout A (register
+// bits are e's bits 0-5) and e = r * 64 + lane in layout B (register bits are e's bits 6-11).  A key
+// is held negated while its block sorts descending, i.e. while bit KK of e is set.
+template <int KK>
+__device__ __forceinline__ void w64_merge(double (&k)[64], double* tile, int lane) {
+    constexpr unsigned SIGN = 0x80000000u;
+    if constexpr (KK <= 5) {
+        // bits KK and KK-1 are register bits: flip where they differ (KK = 1: where bit 1 is set)
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+            const int hi = (r >> KK) & 1, lo = (KK > 1) ? ((r >> (KK - 1)) & 1) : 0;
+            if (hi ^ lo) flip_sign(k[r], SIGN);
+        }
+        w64_substages_down<KK - 1>(k);
+    } else if constexpr (KK == 6) {
+        // bit 6 is lane bit 0, bit 5 a register bit
+        const unsigned m0 = (lane & 1) ? SIGN : 0u, m1 = m0 ^ SIGN;
+#pragma unroll
+        for (int r = 0; r < 64; r++) flip_sign(k[r], (r & 32) ? m1 : m0);
+        w64_substages_down<5>(k);
+    } else {
+        // bits KK-1 .. 6 in layout B, then bits 5 .. 0 in layout A
+        w64_transpose(k, tile, lane);
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+            const int hi = (KK < 12) ? ((r >> (KK - 6)) & 1) : 0, lo = (r >> (KK - 7)) & 1;
+            if (hi ^ lo) flip_sign(k[r], SIGN);
+        }
+        w64_substages_down<KK - 7>(k);
+        w64_transpose(k, tile, lane);
+        w64_substages_down<5>(k);
+    }
+    if constexpr (KK < 12) w64_merge<KK + 1>(k, tile, lane);
+}
+
+// Exact ranks by counting, for the rare example whose near-equal magnitudes the 12-bit payload would
+// misorder: rank_j = 1 + #{i : (|c_i|, i) < (|c_j|, j)}.  tile holds |c| at [column * 65 + row].
+__device__ __forceinline__ void w64_exact_ranks(const double (&y)[64], unsigned (&rank)[64], const double* tile, int lane) {
+#pragma unroll
+    for (int r = 0; r < 64; r++) rank[r] = 1;
+    for (int c = 0; c < 64; c++) {
+        for (int q = 0; q < 64; q++) {
+            const double v = tile[c * 65 + q];
+            const int i = q + 64 * c;
+#pragma unroll
+            for (int r = 0; r < 64; r++) {
+                const double mine = __builtin_fabs(y[r]);
+                const int j = r + 64 * lane;
+                rank[r] += (v < mine || (v == mine && i < j)) ? 1u : 0u;
+            }
+        }
+    }
+}
+
+// Byte offsets inside the wave's tile for the rank hand-over: the low 12 bits of every exact
+// magnitude by element index, (flag | low bits | index) by sorted position, 16-bit ranks by index.
+constexpr int W64_OFF_LOW = 0, W64_OFF_POS = 8192, W64_OFF_RANK = 24576;
+
+// Gini sparsity term and gradient of the coefficients held column-wise (lane = column c, y[r] =
+// Y(r, c), vectorise index r + 64 c).  On exit y holds delta.  Returns S in every lane.
+__device__ __forceinline__ double w64_gini(double (&y)[64], double* tile, int lane_in) {
+    constexpr int n = 4096;
+    // opaque copy of the lane id: keeps the 64 per-element indices from being hoisted out of the
+    // example loop (where they would only be spilled)
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+
+    // The index-in-the-mantissa keys need magnitudes that are zero or normal numbers; the fast sign
+    // needs them inside the range where x / sqrt(x*x) is exactly +-1.  Anything else is rare: the
+    // example then ranks by counting, or evaluates the sign the way the reference writes it.
+    bool odd_rank = false, odd_sign = false;
+#pragma unroll
+    for (int r = 0; r < 64; r++) {
+        const double ay = __builtin_fabs(y[r]);
+        odd_rank |= !((ay == 0.0) | ((ay >= 0x1p-1000) & (ay <= 0x1p1000)));
+        odd_sign |= !((ay == 0.0) | ((ay >= 0x1p-500) & (ay <= 0x1p500)));
+    }
+    odd_rank = __any(odd_rank);
+    odd_sign = __any(odd_sign);
+
+    unsigned short* rk = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(tile) + W64_OFF_RANK);
+    if (!odd_rank) {
+        double k[64];
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+            const double ay = __builtin_fabs(y[r]);
+            const unsigned idx = (unsigned)(r + 64 * lane);
+            k[r] = __hiloint2double(__double2hiint(ay), (int)((((unsigned)__double2loint(ay)) & ~0xFFFu) | idx));
+        }
+        w64_merge<1>(k, tile, lane);
+        // Sorted position p = lane * 64 + r.  Keys that agree in the upper 52 bits (zeros aside) form a
+        // group whose members are in index order and must be put in (exact magnitude, index) order.
+        // gp bit r: position p belongs to the same group as position p - 1.
+        unsigned long long gp = 0;
+        {
+            const double prev_last = __shfl_up(k[63], 1, 64);
+#pragma unroll
+            for (int r = 0; r < 64; r++) {
+                const double prv = (r > 0) ? k[r - 1] : prev_last;
+                const unsigned lo0 = (unsigned)__double2loint(prv), lo1 = (unsigned)__double2loint(k[r]);
+                const int hi1 = __double2hiint(k[r]);
+                const bool same = __double2hiint(prv) == hi1 && ((lo0 ^ lo1) < 4096u) && !(hi1 == 0 && lo1 < 4096u);
+                if (same && (r > 0 || lane > 0)) gp |= 1ull << r;
+            }
+        }
+        const unsigned next_gp0 = __shfl_down((unsigned)(gp & 1ull), 1, 64);
+        const unsigned long long grouped = gp | (gp >> 1) | ((lane < 63 && next_gp0) ? (1ull << 63) : 0ull);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (__any(grouped != 0)) {
+            // low 12 bits of the exact magnitudes, by element index
+            uint4* low4 = reinterpret_cast<uint4*>(reinterpret_cast<char*>(tile) + W64_OFF_LOW) + 8 * lane;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                unsigned wds[4];
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    const unsigned l0 = (unsigned)__double2loint(y[8 * q + 2 * h]) & 0xFFFu;
+                    const unsigned l1 = (unsigned)__double2loint(y[8 * q + 2 * h + 1]) & 0xFFFu;
+                    wds[h] = l0 | (l1 << 16);
+                }
+                low4[q] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // by sorted position: group flag, the 12 low bits, the index
+            const unsigned short* low = reinterpret_cast<const unsigned short*>(reinterpret_cast<char*>(tile) + W64_OFF_LOW);
+            unsigned* pos = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(tile) + W64_OFF_POS);
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                unsigned wds[4];
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    const int r = 4 * q + h;
+                    const unsigned idx = (unsigned)__double2loint(k[r]) & 0xFFFu;
+                    wds[h] = ((unsigned)((gp >> r) & 1ull) << 31) | ((unsigned)low[idx] << 12) | idx;
+                }
+                reinterpret_cast<uint4*>(pos + 64 * lane)[q] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 64; r++) {
+                if (!((grouped >> r) & 1ull)) rk[(unsigned)__double2loint(k[r]) & 0xFFFu] = (unsigned short)(lane * 64 + r + 1);
+            }
+            // members of a group: rank = group start + number of members below in (low bits, index)
+            unsigned long long todo = grouped;
+            while (todo) {
+                const unsigned p = (unsigned)(lane * 64 + __builtin_ctzll(todo));
+                todo &= todo - 1;
+                const unsigned me = pos[p];
+                unsigned gs = p, w = me;
+                while (w >> 31) { gs--; w = pos[gs]; }
+                unsigned below = 0;
+                for (unsigned q = gs; q < (unsigned)n; q++) {
+                    const unsigned o = pos[q];
+                    if (q > gs && !(o >> 31)) break;
+                    below += ((o & 0xFFFFFFu) < (me & 0xFFFFFFu)) ? 1u : 0u;
+                }
+                rk[me & 0xFFFu] = (unsigned short)(gs + below + 1);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 64; r++) rk[(unsigned)__double2loint(k[r]) & 0xFFFu] = (unsigned short)(lane * 64 + r + 1);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 64; r++) tile[lane * 65 + r] = __builtin_fabs(y[r]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        unsigned rank[64];
+        w64_exact_ranks(y, rank, tile, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 64; r++) rk[r + 64 * lane] = (unsigned short)rank[r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint4* rk4 = reinterpret_cast<const uint4*>(rk + 64 * lane);
+    double f = 0, sabs = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const uint4 pk = rk4[q];
+        const unsigned wds[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+        for (int h = 0; h < 8; h++) {
+            const unsigned rank = (wds[h >> 1] >> (16 * (h & 1))) & 0xFFFFu;
+            const double coef = 2.0 * (double)rank - (double)n - 1.0;
+            const double ay = __builtin_fabs(y[8 * q + h]);
+            f = __builtin_fma(coef, ay, f);
+            sabs += ay;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        f += __shfl_xor(f, off, 64);
+        sabs += __shfl_xor(sabs, off, 64);
+    }
+    const double g = (double)n * sabs;
+    const double inv_g2 = 1.0 / (g * g);
+    if (!odd_sign) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint4 pk = rk4[q];
+            const unsigned wds[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+            for (int h = 0; h < 8; h++) {
+                const unsigned rank = (wds[h >> 1] >> (16 * (h & 1))) & 0xFFFFu;
+                const double coef = 2.0 * (double)rank - (double)n - 1.0;
+                const double v = y[8 * q + h];
+                const double sg = (v == 0.0) ? 0.0 : __builtin_copysign(1.0, v);  // == sign_ref in this range
+                y[8 * q + h] = -((coef * sg) * g - f * ((double)n * sg)) * inv_g2;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+            const double coef = 2.0 * (double)rk[r + 64 * lane] - (double)n - 1.0;
+            const double sg = sign_ref(y[r]);
+            y[r] = -((coef * sg) * g - f * ((double)n * sg)) * inv_g2;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return 1.0 - f / g;
+}
+
+// ---- kernel ---------------------------------------------------------------------------------------------
+// 256 threads = 4 waves = 4 examples in flight per workgroup; grid-stride over the batch.
+template <int NP>
+__global__ __launch_bounds__(256, 1) void k_train64(FusedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double* tile = smem + wave * W64_TILE;
+    const FilterDev* filt = A.filt;
+    double a[NP], b[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    const int N = filt->N, dpad = filt->d;
+
+    double accG = 0, accS = 0, accBad = 0;
+    const int nslots = gridDim.x * 4;
+    for (int e = blockIdx.x * 4 + wave; e < A.B; e += nslots) {
+        const double* Xe = A.X + (size_t)e * 4096;
+        double v[64], p[64], w[64];
+        // rows: lane = row, v[c] = X(lane, c)
+#pragma unroll
+        for (int c = 0; c < 64; c++) v[c] = Xe[lane + 64 * c];
+        w64_forward<NP>(v, p, w, a, b);               // w = row-stage coefficients Y1(lane, :)
+        w64_transpose(w, tile, lane);                 // w[r] = Y1(r, lane): lane = column
+        w64_forward<NP>(w, p, v, a, b);               // v = Y(:, lane)
+        const double S = w64_gini(v, tile, lane);     // v = delta(:, lane)
+        w64_pyramid_levels<NP, 5>(w, p, a);           // column pyramid again: cheaper than keeping it over the sort
+
+        double gL[NP], gH[NP];
+#pragma unroll
+        for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
+        w64_bwd_levels<NP, 0, true>(v, w, p, a, b, gL, gH);   // columns; v = errors on Y1(:, lane)
+        w64_transpose(v, tile, lane);                          // v[c] = D1(lane, c): lane = row
+#pragma unroll
+        for (int c = 0; c < 64; c++) w[c] = Xe[lane + 64 * c];
+        w64_pyramid_levels<NP, 5>(w, p, a);
+        w64_bwd_levels<NP, 0, false>(v, w, p, a, b, gL, gH);  // rows
+
+        // tap k' collects gL[k'] and sH[k'] gH[NP-1-k'], summed over the 64 lanes
+        double mine = 0;
+#pragma unroll
+        for (int kp = 0; kp < NP; kp++) {
+            double c = filt->vL[kp] * gL[kp] + filt->sH[kp] * gH[NP - 1 - kp];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+            if (lane == kp) mine = c;
+        }
+        const int k = lane - dpad;
+        if (lane < NP && k >= 0 && k < N) {
+            accG += mine;
+            if (!isfinite(mine)) accBad += 1;
+            if (A.grad) A.grad[(size_t)e * N + k] = mine;
+        }
+        if (lane == 0) {
+            accS += S;
+            if (!isfinite(S)) accBad += 1;
+            if (A.S) A.S[e] = S;
+        }
+    }
+    // per-wave sums: slot = workgroup * 4 + wave
+    double bad = accBad;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, 64);
+    double* part = A.partial + (size_t)(blockIdx.x * 4 + wave) * PSTRIDE;
+    const int k = lane - dpad;
+    if (lane < NP && k >= 0 && k < N) part[k] = accG;
+    if (lane == 0) { part[N] = accS; part[N + 1] = bad; }
+}
+
+}  // namespace wn
