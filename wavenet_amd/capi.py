@@ -68,7 +68,8 @@ class WavenetError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libwavenet_hip.so")
+    """The library next to this package, unless WAVENET_HIP_LIBRARY names another build of it."""
+    return os.environ.get("WAVENET_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libwavenet_hip.so")
 
 
 _lib = None

@@ -23,11 +23,34 @@ namespace wn {
 
 constexpr int W64_TILE = 64 * 65;  // doubles of LDS per wave
 
+// min -> lo, max -> hi.  Plain (not volatile) asm: two instructions, free to be scheduled.
 __device__ __forceinline__ void cmpx_asm(double& lo, double& hi) {
     double mn, mx;
+#ifndef W64_CMPX_PLAIN
     asm volatile("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(mn), "=&v"(mx) : "v"(lo), "v"(hi));
+#else
+    asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(lo), "v"(hi));
+    asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(lo), "v"(hi));
+#endif
     lo = mn;
     hi = mx;
+}
+
+// Parks 64 doubles in accumulation registers until their next use.  The sort needs all the
+// architectural VGPRs it can get; saying where the bystanders go keeps them out of scratch memory,
+// and the opaque asm keeps expressions of them from being carried across in more registers.
+__device__ __forceinline__ void w64_park(double (&v)[64]) {
+#ifdef W64_PARK
+#pragma unroll
+    for (int r = 0; r < 64; r++) asm volatile("" : "+a"(v[r]));
+#endif
+}
+
+// Order point between LDS writes and the reads that follow: a wave's LDS operations execute in
+// order, so only the compiler has to be told.
+__device__ __forceinline__ void w64_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // ---- one line in registers ------------------------------------------------------------------------
@@ -39,9 +62,11 @@ __device__ __forceinline__ double w64_act(const double (&x)[64], const double (&
     else return p[(2 << LG) + idx];
 }
 
-// Forward cascade of a 64-sample line: y = coefficients, p[2^i + k] = low-pass level i (p[0] unused).
-template <int NP, int LG>
-__device__ __forceinline__ void w64_fwd_levels(const double (&x)[64], double (&p)[64], double (&y)[64],
+// Forward cascade of a 64-sample line.  p[2^i + k] = low-pass level i (p[0] unused).  The
+// coefficients (out[0] = lo_0, out[2^i + k] = hi_i[k]) go to y, or with TO_TILE straight to the
+// lane's row of the LDS tile, the first half of a transpose.
+template <int NP, int LG, bool TO_TILE>
+__device__ __forceinline__ void w64_fwd_levels(const double (&x)[64], double (&p)[64], double (&y)[64], double* trow,
                                                const double (&a)[NP], const double (&b)[NP]) {
     constexpr int half = 1 << LG, len = 2 * half;
 #pragma unroll
@@ -55,17 +80,15 @@ __device__ __forceinline__ void w64_fwd_levels(const double (&x)[64], double (&p
             sh = __builtin_fma(b[j], v, sh);
         }
         p[half + k] = sl;
-        y[half + k] = sh;
+        if constexpr (TO_TILE) trow[half + k] = sh;
+        else y[half + k] = sh;
     }
-    if constexpr (LG > 0) w64_fwd_levels<NP, LG - 1>(x, p, y, a, b);
-}
-
-template <int NP>
-__device__ __forceinline__ void w64_forward(const double (&x)[64], double (&p)[64], double (&y)[64],
-                                            const double (&a)[NP], const double (&b)[NP]) {
-    w64_fwd_levels<NP, 5>(x, p, y, a, b);
-    y[0] = p[1];
-    p[0] = 0;
+    if constexpr (LG > 0) {
+        w64_fwd_levels<NP, LG - 1, TO_TILE>(x, p, y, trow, a, b);
+    } else {
+        if constexpr (TO_TILE) trow[0] = p[1];
+        else y[0] = p[1];
+    }
 }
 
 // Low-pass pyramid only, levels 5..1 (what the backward pass reads).
@@ -85,9 +108,11 @@ __device__ __forceinline__ void w64_pyramid_levels(const double (&x)[64], double
     if constexpr (LG > 1) w64_pyramid_levels<NP, LG - 1>(x, p, a);
 }
 
-// Backward cascade of a line, levels LG = 0..5 (src/Wavenet.cxx:509-545): d in place.
-template <int NP, int LG, bool LASTPROP>
-__device__ __forceinline__ void w64_bwd_levels(double (&d)[64], const double (&x)[64], const double (&p)[64],
+// Backward cascade of a line, levels LG = 0..5 (src/Wavenet.cxx:509-545): d in place.  At the top
+// level the errors on the line's input are either not needed (TOP_TO_TILE false: row stage) or go
+// straight to the lane's row of the LDS tile (column stage: first half of the transpose).
+template <int NP, int LG, bool TOP_TO_TILE>
+__device__ __forceinline__ void w64_bwd_levels(double (&d)[64], const double (&x)[64], const double (&p)[64], double* trow,
                                                const double (&a)[NP], const double (&b)[NP],
                                                double (&gL)[NP], double (&gH)[NP]) {
     constexpr int len = 1 << LG, alen = 2 * len;
@@ -102,11 +127,11 @@ __device__ __forceinline__ void w64_bwd_levels(double (&d)[64], const double (&x
             gH[u] = __builtin_fma(dh, v, gH[u]);
         }
     }
-    if constexpr (LG < 5 || LASTPROP) {
+    if constexpr (LG < 5 || TOP_TO_TILE) {
         constexpr int S = NP / 2;
         constexpr int JE = S & 1, JO = (S + 1) & 1;
         constexpr int CE = (JE - S) / 2, CO = (1 + JO - S) / 2;
-        double nw[alen];
+        double nw[LG < 5 ? alen : 2];
 #pragma unroll
         for (int q = 0; q < len; q++) {
             double se = 0, so = 0;
@@ -118,28 +143,36 @@ __device__ __forceinline__ void w64_bwd_levels(double (&d)[64], const double (&x
                 so = __builtin_fma(a[JO + 2 * i], d[ro], so);
                 so = __builtin_fma(b[JO + 2 * i], d[len + ro], so);
             }
-            nw[2 * q] = se;
-            nw[2 * q + 1] = so;
+            if constexpr (LG < 5) {
+                nw[2 * q] = se;
+                nw[2 * q + 1] = so;
+            } else {
+                trow[2 * q] = se;
+                trow[2 * q + 1] = so;
+            }
         }
+        if constexpr (LG < 5) {
 #pragma unroll
-        for (int c = 0; c < alen; c++) d[c] = nw[c];
+            for (int c = 0; c < alen; c++) d[c] = nw[c];
+        }
     }
-    if constexpr (LG < 5) w64_bwd_levels<NP, LG + 1, LASTPROP>(d, x, p, a, b, gL, gH);
+    if constexpr (LG < 5) w64_bwd_levels<NP, LG + 1, TOP_TO_TILE>(d, x, p, trow, a, b, gL, gH);
 }
 
 // ---- 64x64 transpose through the wave's LDS tile -----------------------------------------------------
-// v[r] of lane l  ->  v[l] of lane r.  Row stride 65 doubles: conflict-free both ways.  A wave's LDS
-// operations execute in order, so no barrier is needed; the fence keeps the compiler from moving
-// the reads above the writes.
+// Row stride 65 doubles: conflict-free both ways.  No fence between the writes and the reads: both
+// are accesses to doubles that may alias as far as the compiler can tell, so it keeps their program
+// order, and the LDS executes a wave's operations in order -- while the scheduler stays free to
+// overlap the transfers with the arithmetic on either side.
+__device__ __forceinline__ void w64_read_transposed(double (&v)[64], const double* tile, int lane) {
+#pragma unroll
+    for (int r = 0; r < 64; r++) v[r] = tile[r * 65 + lane];
+}
+// v[r] of lane l  ->  v[l] of lane r
 __device__ __forceinline__ void w64_transpose(double (&v)[64], double* tile, int lane) {
 #pragma unroll
     for (int r = 0; r < 64; r++) tile[lane * 65 + r] = v[r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int r = 0; r < 64; r++) v[r] = tile[r * 65 + lane];
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    w64_read_transposed(v, tile, lane);
 }
 
 // ---- sort ---------------------------------------------------------------------------------------------
@@ -215,13 +248,15 @@ __device__ __forceinline__ void w64_exact_ranks(const double (&y)[64], unsigned 
     }
 }
 
-// Byte offsets inside the wave's tile for the rank hand-over: the low 12 bits of every exact
-// magnitude by element index, (flag | low bits | index) by sorted position, 16-bit ranks by index.
-constexpr int W64_OFF_LOW = 0, W64_OFF_POS = 8192, W64_OFF_RANK = 24576;
+// Byte offsets inside the wave's tile for the rank hand-over, three tables of 4096 16-bit entries:
+// the low 12 bits of every exact magnitude by element index, (group flag | index) by sorted
+// position, ranks by element index.
+constexpr int W64_OFF_LOW = 0, W64_OFF_POS = 8192, W64_OFF_RANK = 16384;
 
 // Gini sparsity term and gradient of the coefficients held column-wise (lane = column c, y[r] =
-// Y(r, c), vectorise index r + 64 c).  On exit y holds delta.  Returns S in every lane.
-__device__ __forceinline__ double w64_gini(double (&y)[64], double* tile, int lane_in) {
+// Y(r, c), vectorise index r + 64 c).  On exit y holds delta.  `bystander` is parked in accumulation
+// registers for the duration of the sort.  Returns S in every lane.
+__device__ __forceinline__ double w64_gini(double (&y)[64], double (&bystander)[64], double* tile, int lane_in) {
     constexpr int n = 4096;
     // opaque copy of the lane id: keeps the 64 per-element indices from being hoisted out of the
     // example loop (where they would only be spilled)
@@ -250,27 +285,30 @@ __device__ __forceinline__ double w64_gini(double (&y)[64], double* tile, int la
             const unsigned idx = (unsigned)(r + 64 * lane);
             k[r] = __hiloint2double(__double2hiint(ay), (int)((((unsigned)__double2loint(ay)) & ~0xFFFu) | idx));
         }
+        w64_park(y);
+        w64_park(bystander);
         w64_merge<1>(k, tile, lane);
-        // Sorted position p = lane * 64 + r.  Keys that agree in the upper 52 bits (zeros aside) form a
-        // group whose members are in index order and must be put in (exact magnitude, index) order.
-        // gp bit r: position p belongs to the same group as position p - 1.
+        // Sorted position p = lane * 64 + r.  Everyone gets rank p + 1 first.
+        w64_lds_order();
+#pragma unroll
+        for (int r = 0; r < 64; r++) rk[(unsigned)__double2loint(k[r]) & 0xFFFu] = (unsigned short)(lane * 64 + r + 1);
+        // Keys that agree in the upper 52 bits (zeros aside) form a group whose members are in index
+        // order and must be put in (exact magnitude, index) order.  gp bit r: position p belongs to the
+        // same group as position p - 1.
         unsigned long long gp = 0;
         {
             const double prev_last = __shfl_up(k[63], 1, 64);
 #pragma unroll
             for (int r = 0; r < 64; r++) {
-                const double prv = (r > 0) ? k[r - 1] : prev_last;
-                const unsigned lo0 = (unsigned)__double2loint(prv), lo1 = (unsigned)__double2loint(k[r]);
-                const int hi1 = __double2hiint(k[r]);
-                const bool same = __double2hiint(prv) == hi1 && ((lo0 ^ lo1) < 4096u) && !(hi1 == 0 && lo1 < 4096u);
-                if (same && (r > 0 || lane > 0)) gp |= 1ull << r;
+                const unsigned long long kb = (unsigned long long)__double_as_longlong(k[r]);
+                const unsigned long long pb = (unsigned long long)__double_as_longlong((r > 0) ? k[r - 1] : prev_last);
+                const bool same = ((pb ^ kb) < 4096ull) & (kb >= 4096ull) & ((r > 0) | (lane > 0));
+                gp |= same ? (1ull << r) : 0ull;
             }
         }
-        const unsigned next_gp0 = __shfl_down((unsigned)(gp & 1ull), 1, 64);
-        const unsigned long long grouped = gp | (gp >> 1) | ((lane < 63 && next_gp0) ? (1ull << 63) : 0ull);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (__any(grouped != 0)) {
+        if (__any(gp != 0)) {
+            const unsigned next_gp0 = __shfl_down((unsigned)(gp & 1ull), 1, 64);
+            const unsigned long long grouped = gp | (gp >> 1) | ((lane < 63 && next_gp0) ? (1ull << 63) : 0ull);
             // low 12 bits of the exact magnitudes, by element index
             uint4* low4 = reinterpret_cast<uint4*>(reinterpret_cast<char*>(tile) + W64_OFF_LOW) + 8 * lane;
 #pragma unroll
@@ -284,62 +322,52 @@ __device__ __forceinline__ double w64_gini(double (&y)[64], double* tile, int la
                 }
                 low4[q] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // by sorted position: group flag, the 12 low bits, the index
-            const unsigned short* low = reinterpret_cast<const unsigned short*>(reinterpret_cast<char*>(tile) + W64_OFF_LOW);
-            unsigned* pos = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(tile) + W64_OFF_POS);
+            // by sorted position: group flag and index
+            unsigned short* pos = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(tile) + W64_OFF_POS);
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
+            for (int q = 0; q < 8; q++) {
                 unsigned wds[4];
 #pragma unroll
                 for (int h = 0; h < 4; h++) {
-                    const int r = 4 * q + h;
-                    const unsigned idx = (unsigned)__double2loint(k[r]) & 0xFFFu;
-                    wds[h] = ((unsigned)((gp >> r) & 1ull) << 31) | ((unsigned)low[idx] << 12) | idx;
+                    const int r = 8 * q + 2 * h;
+                    const unsigned e0 = ((unsigned)__double2loint(k[r]) & 0xFFFu) | ((unsigned)((gp >> r) & 1ull) << 15);
+                    const unsigned e1 = ((unsigned)__double2loint(k[r + 1]) & 0xFFFu) | ((unsigned)((gp >> (r + 1)) & 1ull) << 15);
+                    wds[h] = e0 | (e1 << 16);
                 }
                 reinterpret_cast<uint4*>(pos + 64 * lane)[q] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 64; r++) {
-                if (!((grouped >> r) & 1ull)) rk[(unsigned)__double2loint(k[r]) & 0xFFFu] = (unsigned short)(lane * 64 + r + 1);
-            }
+            w64_lds_order();
             // members of a group: rank = group start + number of members below in (low bits, index)
+            const unsigned short* low = reinterpret_cast<const unsigned short*>(reinterpret_cast<char*>(tile) + W64_OFF_LOW);
             unsigned long long todo = grouped;
             while (todo) {
                 const unsigned p = (unsigned)(lane * 64 + __builtin_ctzll(todo));
                 todo &= todo - 1;
                 const unsigned me = pos[p];
+                const unsigned mine = ((unsigned)low[me & 0xFFFu] << 12) | (me & 0xFFFu);
                 unsigned gs = p, w = me;
-                while (w >> 31) { gs--; w = pos[gs]; }
+                while (w >> 15) { gs--; w = pos[gs]; }
                 unsigned below = 0;
                 for (unsigned q = gs; q < (unsigned)n; q++) {
                     const unsigned o = pos[q];
-                    if (q > gs && !(o >> 31)) break;
-                    below += ((o & 0xFFFFFFu) < (me & 0xFFFFFFu)) ? 1u : 0u;
+                    if (q > gs && !(o >> 15)) break;
+                    const unsigned other = ((unsigned)low[o & 0xFFFu] << 12) | (o & 0xFFFu);
+                    below += (other < mine) ? 1u : 0u;
                 }
                 rk[me & 0xFFFu] = (unsigned short)(gs + below + 1);
             }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 64; r++) rk[(unsigned)__double2loint(k[r]) & 0xFFFu] = (unsigned short)(lane * 64 + r + 1);
         }
     } else {
 #pragma unroll
         for (int r = 0; r < 64; r++) tile[lane * 65 + r] = __builtin_fabs(y[r]);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        w64_lds_order();
         unsigned rank[64];
         w64_exact_ranks(y, rank, tile, lane);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        w64_lds_order();
 #pragma unroll
         for (int r = 0; r < 64; r++) rk[r + 64 * lane] = (unsigned short)rank[r];
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    w64_lds_order();
     const uint4* rk4 = reinterpret_cast<const uint4*>(rk + 64 * lane);
     double f = 0, sabs = 0;
 #pragma unroll
@@ -384,8 +412,7 @@ __device__ __forceinline__ double w64_gini(double (&y)[64], double* tile, int la
             y[r] = -((coef * sg) * g - f * ((double)n * sg)) * inv_g2;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    w64_lds_order();
     return 1.0 - f / g;
 }
 
@@ -395,7 +422,6 @@ template <int NP>
 __global__ __launch_bounds__(256, 1) void k_train64(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double* tile = smem + wave * W64_TILE;
     const FilterDev* filt = A.filt;
     double a[NP], b[NP];
 #pragma unroll
@@ -406,25 +432,31 @@ __global__ __launch_bounds__(256, 1) void k_train64(FusedArgs A) {
     const int nslots = gridDim.x * 4;
     for (int e = blockIdx.x * 4 + wave; e < A.B; e += nslots) {
         const double* Xe = A.X + (size_t)e * 4096;
-        double v[64], p[64], w[64];
-        // rows: lane = row, v[c] = X(lane, c)
+        // LDS addresses are rebuilt from an opaque offset every iteration: hoisted out of the loop
+        // they would only occupy registers (or scratch) all the way through
+        unsigned tile_off = (unsigned)wave * W64_TILE;
+        asm volatile("" : "+v"(tile_off));
+        double* tile = smem + tile_off;
+        double* trow = tile + lane * 65;
+        double v[64], w[64], p[64];
+        // rows: lane = row, v[c] = X(lane, c); the row-stage coefficients Y1(lane, :) go to the tile
 #pragma unroll
         for (int c = 0; c < 64; c++) v[c] = Xe[lane + 64 * c];
-        w64_forward<NP>(v, p, w, a, b);               // w = row-stage coefficients Y1(lane, :)
-        w64_transpose(w, tile, lane);                 // w[r] = Y1(r, lane): lane = column
-        w64_forward<NP>(w, p, v, a, b);               // v = Y(:, lane)
-        const double S = w64_gini(v, tile, lane);     // v = delta(:, lane)
-        w64_pyramid_levels<NP, 5>(w, p, a);           // column pyramid again: cheaper than keeping it over the sort
+        w64_fwd_levels<NP, 5, true>(v, p, w, trow, a, b);
+        w64_read_transposed(w, tile, lane);                  // w[r] = Y1(r, lane): lane = column
+        w64_fwd_levels<NP, 5, false>(w, p, v, trow, a, b);   // v = Y(:, lane)
+        const double S = w64_gini(v, w, tile, lane);         // v = delta(:, lane)
+        w64_pyramid_levels<NP, 5>(w, p, a);                  // column pyramid again: cheaper than keeping it over the sort
 
         double gL[NP], gH[NP];
 #pragma unroll
         for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
-        w64_bwd_levels<NP, 0, true>(v, w, p, a, b, gL, gH);   // columns; v = errors on Y1(:, lane)
-        w64_transpose(v, tile, lane);                          // v[c] = D1(lane, c): lane = row
+        w64_bwd_levels<NP, 0, true>(v, w, p, trow, a, b, gL, gH);   // columns; errors on Y1(:, lane) to the tile
+        w64_read_transposed(v, tile, lane);                         // v[c] = D1(lane, c): lane = row
 #pragma unroll
         for (int c = 0; c < 64; c++) w[c] = Xe[lane + 64 * c];
         w64_pyramid_levels<NP, 5>(w, p, a);
-        w64_bwd_levels<NP, 0, false>(v, w, p, a, b, gL, gH);  // rows
+        w64_bwd_levels<NP, 0, false>(v, w, p, trow, a, b, gL, gH);  // rows
 
         // tap k' collects gL[k'] and sH[k'] gH[NP-1-k'], summed over the 64 lanes
         double mine = 0;
