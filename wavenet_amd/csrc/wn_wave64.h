@@ -91,9 +91,10 @@ __device__ __forceinline__ void w64_fwd_levels(const double (&x)[64], double (&p
     }
 }
 
-// Low-pass pyramid only, levels 5..1 (what the backward pass reads).
+// Low-pass pyramid only, levels 5..1 (what the backward pass reads), written to the lane's row of the
+// LDS tile: trow[2^i + k] = lo_i[k].  Registers hold a level only until the next one is computed.
 template <int NP, int LG>
-__device__ __forceinline__ void w64_pyramid_levels(const double (&x)[64], double (&p)[64], const double (&a)[NP]) {
+__device__ __forceinline__ void w64_pyramid_to_tile(const double (&x)[64], double (&p)[64], double* trow, const double (&a)[NP]) {
     constexpr int half = 1 << LG, len = 2 * half;
 #pragma unroll
     for (int k = 0; k < half; k++) {
@@ -104,25 +105,35 @@ __device__ __forceinline__ void w64_pyramid_levels(const double (&x)[64], double
             sl = __builtin_fma(a[j], w64_act<LG>(x, p, idx), sl);
         }
         p[half + k] = sl;
+        trow[half + k] = sl;
     }
-    if constexpr (LG > 1) w64_pyramid_levels<NP, LG - 1>(x, p, a);
+    if constexpr (LG > 1) w64_pyramid_to_tile<NP, LG - 1>(x, p, trow, a);
 }
 
-// Backward cascade of a line, levels LG = 0..5 (src/Wavenet.cxx:509-545): d in place.  At the top
-// level the errors on the line's input are either not needed (TOP_TO_TILE false: row stage) or go
-// straight to the lane's row of the LDS tile (column stage: first half of the transpose).
+// Backward cascade of a line, levels LG = 0..5 (src/Wavenet.cxx:509-545): d in place.  The
+// activations below the top level come from the lane's row of the LDS tile (w64_pyramid_to_tile).
+// At the top level the errors on the line's input are either not needed (TOP_TO_TILE false: row
+// stage) or go straight to that row (column stage: first half of the transpose) -- after the last
+// read of the pyramid, which the in-order LDS keeps safe.
 template <int NP, int LG, bool TOP_TO_TILE>
-__device__ __forceinline__ void w64_bwd_levels(double (&d)[64], const double (&x)[64], const double (&p)[64], double* trow,
+__device__ __forceinline__ void w64_bwd_levels(double (&d)[64], const double (&x)[64], double* trow,
                                                const double (&a)[NP], const double (&b)[NP],
                                                double (&gL)[NP], double (&gH)[NP]) {
     constexpr int len = 1 << LG, alen = 2 * len;
+    double act[LG < 5 ? alen : 1];
+    if constexpr (LG < 5) {
+#pragma unroll
+        for (int i = 0; i < alen; i++) act[i] = trow[alen + i];
+    }
 #pragma unroll
     for (int r = 0; r < len; r++) {
         const double dl = d[r], dh = d[len + r];
 #pragma unroll
         for (int u = 0; u < NP; u++) {
             const int idx = (2 * r + NP / 2 - u) & (alen - 1);
-            const double v = w64_act<LG>(x, p, idx);
+            double v;
+            if constexpr (LG == 5) v = x[idx];
+            else v = act[idx];
             gL[u] = __builtin_fma(dl, v, gL[u]);
             gH[u] = __builtin_fma(dh, v, gH[u]);
         }
@@ -156,7 +167,7 @@ __device__ __forceinline__ void w64_bwd_levels(double (&d)[64], const double (&x
             for (int c = 0; c < alen; c++) d[c] = nw[c];
         }
     }
-    if constexpr (LG < 5) w64_bwd_levels<NP, LG + 1, TOP_TO_TILE>(d, x, p, trow, a, b, gL, gH);
+    if constexpr (LG < 5) w64_bwd_levels<NP, LG + 1, TOP_TO_TILE>(d, x, trow, a, b, gL, gH);
 }
 
 // ---- 64x64 transpose through the wave's LDS tile -----------------------------------------------------
@@ -170,6 +181,9 @@ __device__ __forceinline__ void w64_read_transposed(double (&v)[64], const doubl
 }
 // v[r] of lane l  ->  v[l] of lane r
 __device__ __forceinline__ void w64_transpose(double (&v)[64], double* tile, int lane) {
+#ifdef W64_SKIP_TRANSPOSE
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < 64; r++) tile[lane * 65 + r] = v[r];
     w64_read_transposed(v, tile, lane);
@@ -185,7 +199,9 @@ template <int RB>
 __device__ __forceinline__ void w64_substage(double (&k)[64]) {
 #pragma unroll
     for (int r = 0; r < 64; r++) {
+#ifndef W64_SKIP_CMPX
         if (!(r & (1 << RB))) cmpx_asm(k[r], k[r | (1 << RB)]);
+#endif
     }
 }
 template <int RB>
@@ -253,19 +269,26 @@ __device__ __forceinline__ void w64_exact_ranks(const double (&y)[64], unsigned 
 // position, ranks by element index.
 constexpr int W64_OFF_LOW = 0, W64_OFF_POS = 8192, W64_OFF_RANK = 16384;
 
-// Gini sparsity term and gradient of the coefficients held column-wise (lane = column c, y[r] =
-// Y(r, c), vectorise index r + 64 c).  On exit y holds delta.  `bystander` is parked in accumulation
-// registers for the duration of the sort.  Returns S in every lane.
-__device__ __forceinline__ double w64_gini(double (&y)[64], double (&bystander)[64], double* tile, int lane_in) {
-    constexpr int n = 4096;
+// What the sorting half of the Gini phase hands to the finishing half.
+struct W64Rank {
+    bool odd_rank;              // some magnitude is neither zero nor a normal number: rank by counting
+    bool odd_sign;              // some magnitude is outside the range where the fast sign is exact
+    bool any_group;             // some keys agree in their upper 52 bits: re-rank those groups
+    unsigned long long grouped; // bit r: sorted position lane * 64 + r belongs to such a group
+};
+
+// First half of the Gini phase: sorts the keys of the coefficients y (lane = column c, y[r] =
+// Y(r, c), vectorise index r + 64 c) and leaves a provisional rank for every element in the tile.
+// Needs nothing of y afterwards, so the caller can let it go and recompute it: 64 fewer live
+// doubles during the sort are worth far more than the 504 multiply-adds.
+__device__ __forceinline__ W64Rank w64_rank_sort(const double (&y)[64], double* tile, int lane_in) {
     // opaque copy of the lane id: keeps the 64 per-element indices from being hoisted out of the
     // example loop (where they would only be spilled)
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
-
+    W64Rank R;
     // The index-in-the-mantissa keys need magnitudes that are zero or normal numbers; the fast sign
-    // needs them inside the range where x / sqrt(x*x) is exactly +-1.  Anything else is rare: the
-    // example then ranks by counting, or evaluates the sign the way the reference writes it.
+    // needs them inside the range where x / sqrt(x*x) is exactly +-1.  Anything else is rare.
     bool odd_rank = false, odd_sign = false;
 #pragma unroll
     for (int r = 0; r < 64; r++) {
@@ -273,91 +296,71 @@ __device__ __forceinline__ double w64_gini(double (&y)[64], double (&bystander)[
         odd_rank |= !((ay == 0.0) | ((ay >= 0x1p-1000) & (ay <= 0x1p1000)));
         odd_sign |= !((ay == 0.0) | ((ay >= 0x1p-500) & (ay <= 0x1p500)));
     }
-    odd_rank = __any(odd_rank);
-    odd_sign = __any(odd_sign);
+    R.odd_rank = __any(odd_rank);
+    R.odd_sign = __any(odd_sign);
+    R.any_group = false;
+    R.grouped = 0;
+    if (R.odd_rank) return R;
 
+    double k[64];
+#pragma unroll
+    for (int r = 0; r < 64; r++) {
+        const double ay = __builtin_fabs(y[r]);
+        const unsigned idx = (unsigned)(r + 64 * lane);
+        k[r] = __hiloint2double(__double2hiint(ay), (int)((((unsigned)__double2loint(ay)) & ~0xFFFu) | idx));
+    }
+#ifndef W64_SKIP_SORT
+    w64_merge<1>(k, tile, lane);
+#endif
+    // Sorted position p = lane * 64 + r.  Everyone gets rank p + 1 first.
+    w64_lds_order();
     unsigned short* rk = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(tile) + W64_OFF_RANK);
-    if (!odd_rank) {
-        double k[64];
+#pragma unroll
+    for (int r = 0; r < 64; r++) rk[(unsigned)__double2loint(k[r]) & 0xFFFu] = (unsigned short)(lane * 64 + r + 1);
+    // Keys that agree in the upper 52 bits (zeros aside) form a group whose members are in index
+    // order and must be put in (exact magnitude, index) order.  gp bit r: position p belongs to the
+    // same group as position p - 1.
+    unsigned long long gp = 0;
+    {
+        const double prev_last = __shfl_up(k[63], 1, 64);
 #pragma unroll
         for (int r = 0; r < 64; r++) {
-            const double ay = __builtin_fabs(y[r]);
-            const unsigned idx = (unsigned)(r + 64 * lane);
-            k[r] = __hiloint2double(__double2hiint(ay), (int)((((unsigned)__double2loint(ay)) & ~0xFFFu) | idx));
+            const unsigned long long kb = (unsigned long long)__double_as_longlong(k[r]);
+            const unsigned long long pb = (unsigned long long)__double_as_longlong((r > 0) ? k[r - 1] : prev_last);
+            const bool same = ((pb ^ kb) < 4096ull) & (kb >= 4096ull) & ((r > 0) | (lane > 0));
+            gp |= same ? (1ull << r) : 0ull;
         }
-        w64_park(y);
-        w64_park(bystander);
-        w64_merge<1>(k, tile, lane);
-        // Sorted position p = lane * 64 + r.  Everyone gets rank p + 1 first.
-        w64_lds_order();
+    }
+    R.any_group = __any(gp != 0);
+    if (R.any_group) {
+        const unsigned next_gp0 = __shfl_down((unsigned)(gp & 1ull), 1, 64);
+        R.grouped = gp | (gp >> 1) | ((lane < 63 && next_gp0) ? (1ull << 63) : 0ull);
+        // by sorted position: group flag and index
+        unsigned short* pos = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(tile) + W64_OFF_POS);
 #pragma unroll
-        for (int r = 0; r < 64; r++) rk[(unsigned)__double2loint(k[r]) & 0xFFFu] = (unsigned short)(lane * 64 + r + 1);
-        // Keys that agree in the upper 52 bits (zeros aside) form a group whose members are in index
-        // order and must be put in (exact magnitude, index) order.  gp bit r: position p belongs to the
-        // same group as position p - 1.
-        unsigned long long gp = 0;
-        {
-            const double prev_last = __shfl_up(k[63], 1, 64);
+        for (int q = 0; q < 8; q++) {
+            unsigned wds[4];
 #pragma unroll
-            for (int r = 0; r < 64; r++) {
-                const unsigned long long kb = (unsigned long long)__double_as_longlong(k[r]);
-                const unsigned long long pb = (unsigned long long)__double_as_longlong((r > 0) ? k[r - 1] : prev_last);
-                const bool same = ((pb ^ kb) < 4096ull) & (kb >= 4096ull) & ((r > 0) | (lane > 0));
-                gp |= same ? (1ull << r) : 0ull;
+            for (int h = 0; h < 4; h++) {
+                const int r = 8 * q + 2 * h;
+                const unsigned e0 = ((unsigned)__double2loint(k[r]) & 0xFFFu) | ((unsigned)((gp >> r) & 1ull) << 15);
+                const unsigned e1 = ((unsigned)__double2loint(k[r + 1]) & 0xFFFu) | ((unsigned)((gp >> (r + 1)) & 1ull) << 15);
+                wds[h] = e0 | (e1 << 16);
             }
+            reinterpret_cast<uint4*>(pos + 64 * lane)[q] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
         }
-        if (__any(gp != 0)) {
-            const unsigned next_gp0 = __shfl_down((unsigned)(gp & 1ull), 1, 64);
-            const unsigned long long grouped = gp | (gp >> 1) | ((lane < 63 && next_gp0) ? (1ull << 63) : 0ull);
-            // low 12 bits of the exact magnitudes, by element index
-            uint4* low4 = reinterpret_cast<uint4*>(reinterpret_cast<char*>(tile) + W64_OFF_LOW) + 8 * lane;
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                unsigned wds[4];
-#pragma unroll
-                for (int h = 0; h < 4; h++) {
-                    const unsigned l0 = (unsigned)__double2loint(y[8 * q + 2 * h]) & 0xFFFu;
-                    const unsigned l1 = (unsigned)__double2loint(y[8 * q + 2 * h + 1]) & 0xFFFu;
-                    wds[h] = l0 | (l1 << 16);
-                }
-                low4[q] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
-            }
-            // by sorted position: group flag and index
-            unsigned short* pos = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(tile) + W64_OFF_POS);
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                unsigned wds[4];
-#pragma unroll
-                for (int h = 0; h < 4; h++) {
-                    const int r = 8 * q + 2 * h;
-                    const unsigned e0 = ((unsigned)__double2loint(k[r]) & 0xFFFu) | ((unsigned)((gp >> r) & 1ull) << 15);
-                    const unsigned e1 = ((unsigned)__double2loint(k[r + 1]) & 0xFFFu) | ((unsigned)((gp >> (r + 1)) & 1ull) << 15);
-                    wds[h] = e0 | (e1 << 16);
-                }
-                reinterpret_cast<uint4*>(pos + 64 * lane)[q] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
-            }
-            w64_lds_order();
-            // members of a group: rank = group start + number of members below in (low bits, index)
-            const unsigned short* low = reinterpret_cast<const unsigned short*>(reinterpret_cast<char*>(tile) + W64_OFF_LOW);
-            unsigned long long todo = grouped;
-            while (todo) {
-                const unsigned p = (unsigned)(lane * 64 + __builtin_ctzll(todo));
-                todo &= todo - 1;
-                const unsigned me = pos[p];
-                const unsigned mine = ((unsigned)low[me & 0xFFFu] << 12) | (me & 0xFFFu);
-                unsigned gs = p, w = me;
-                while (w >> 15) { gs--; w = pos[gs]; }
-                unsigned below = 0;
-                for (unsigned q = gs; q < (unsigned)n; q++) {
-                    const unsigned o = pos[q];
-                    if (q > gs && !(o >> 15)) break;
-                    const unsigned other = ((unsigned)low[o & 0xFFFu] << 12) | (o & 0xFFFu);
-                    below += (other < mine) ? 1u : 0u;
-                }
-                rk[me & 0xFFFu] = (unsigned short)(gs + below + 1);
-            }
-        }
-    } else {
+    }
+    return R;
+}
+
+// Second half: from the coefficients y (again) and the ranks in the tile, the sparsity term (return
+// value, in every lane) and its gradient, which replaces y.
+__device__ __forceinline__ double w64_gini_finish(double (&y)[64], const W64Rank& R, double* tile, int lane_in) {
+    constexpr int n = 4096;
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    unsigned short* rk = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(tile) + W64_OFF_RANK);
+    if (R.odd_rank) {
 #pragma unroll
         for (int r = 0; r < 64; r++) tile[lane * 65 + r] = __builtin_fabs(y[r]);
         w64_lds_order();
@@ -366,6 +369,41 @@ __device__ __forceinline__ double w64_gini(double (&y)[64], double (&bystander)[
         w64_lds_order();
 #pragma unroll
         for (int r = 0; r < 64; r++) rk[r + 64 * lane] = (unsigned short)rank[r];
+    } else if (R.any_group) {
+        // low 12 bits of the exact magnitudes, by element index
+        uint4* low4 = reinterpret_cast<uint4*>(reinterpret_cast<char*>(tile) + W64_OFF_LOW) + 8 * lane;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            unsigned wds[4];
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                const unsigned l0 = (unsigned)__double2loint(y[8 * q + 2 * h]) & 0xFFFu;
+                const unsigned l1 = (unsigned)__double2loint(y[8 * q + 2 * h + 1]) & 0xFFFu;
+                wds[h] = l0 | (l1 << 16);
+            }
+            low4[q] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+        }
+        w64_lds_order();
+        // members of a group: rank = group start + number of members below in (low bits, index)
+        const unsigned short* low = reinterpret_cast<const unsigned short*>(reinterpret_cast<char*>(tile) + W64_OFF_LOW);
+        const unsigned short* pos = reinterpret_cast<const unsigned short*>(reinterpret_cast<char*>(tile) + W64_OFF_POS);
+        unsigned long long todo = R.grouped;
+        while (todo) {
+            const unsigned p = (unsigned)(lane * 64 + __builtin_ctzll(todo));
+            todo &= todo - 1;
+            const unsigned me = pos[p];
+            const unsigned mine = ((unsigned)low[me & 0xFFFu] << 12) | (me & 0xFFFu);
+            unsigned gs = p, w = me;
+            while (w >> 15) { gs--; w = pos[gs]; }
+            unsigned below = 0;
+            for (unsigned q = gs; q < (unsigned)n; q++) {
+                const unsigned o = pos[q];
+                if (q > gs && !(o >> 15)) break;
+                const unsigned other = ((unsigned)low[o & 0xFFFu] << 12) | (o & 0xFFFu);
+                below += (other < mine) ? 1u : 0u;
+            }
+            rk[me & 0xFFFu] = (unsigned short)(gs + below + 1);
+        }
     }
     w64_lds_order();
     const uint4* rk4 = reinterpret_cast<const uint4*>(rk + 64 * lane);
@@ -390,7 +428,7 @@ __device__ __forceinline__ double w64_gini(double (&y)[64], double (&bystander)[
     }
     const double g = (double)n * sabs;
     const double inv_g2 = 1.0 / (g * g);
-    if (!odd_sign) {
+    if (!R.odd_sign) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const uint4 pk = rk4[q];
@@ -416,12 +454,27 @@ __device__ __forceinline__ double w64_gini(double (&y)[64], double (&bystander)[
     return 1.0 - f / g;
 }
 
+// One example row-wise into registers: v[c] = X(lane, c).  Eight scalar bases 4 KiB apart, so that
+// every load is scalar base + lane offset + immediate and no per-lane 64-bit address is kept.
+__device__ __forceinline__ void w64_load_rows(double (&v)[64], const double* Xe, int lane) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        typedef const __attribute__((address_space(1))) double* global_ptr;
+        global_ptr bj = (global_ptr)(Xe + 512 * j);
+        asm volatile("" : "+s"(bj));
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[8 * j + c] = bj[lane + 64 * c];
+    }
+}
+
 // ---- kernel ---------------------------------------------------------------------------------------------
 // 256 threads = 4 waves = 4 examples in flight per workgroup; grid-stride over the batch.
 template <int NP>
 __global__ __launch_bounds__(256, 1) void k_train64(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a scalar: example addresses then live in SGPRs and the loads take the
+    // scalar-base form, instead of 64-bit per-lane addresses that end up in scratch memory
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const FilterDev* filt = A.filt;
     double a[NP], b[NP];
 #pragma unroll
@@ -435,28 +488,34 @@ __global__ __launch_bounds__(256, 1) void k_train64(FusedArgs A) {
         // LDS addresses are rebuilt from an opaque offset every iteration: hoisted out of the loop
         // they would only occupy registers (or scratch) all the way through
         unsigned tile_off = (unsigned)wave * W64_TILE;
-        asm volatile("" : "+v"(tile_off));
+        asm volatile("" : "+s"(tile_off));
         double* tile = smem + tile_off;
         double* trow = tile + lane * 65;
         double v[64], w[64], p[64];
         // rows: lane = row, v[c] = X(lane, c); the row-stage coefficients Y1(lane, :) go to the tile
-#pragma unroll
-        for (int c = 0; c < 64; c++) v[c] = Xe[lane + 64 * c];
+        w64_load_rows(v, Xe, lane);
         w64_fwd_levels<NP, 5, true>(v, p, w, trow, a, b);
         w64_read_transposed(w, tile, lane);                  // w[r] = Y1(r, lane): lane = column
         w64_fwd_levels<NP, 5, false>(w, p, v, trow, a, b);   // v = Y(:, lane)
-        const double S = w64_gini(v, w, tile, lane);         // v = delta(:, lane)
-        w64_pyramid_levels<NP, 5>(w, p, a);                  // column pyramid again: cheaper than keeping it over the sort
+        const W64Rank rank = w64_rank_sort(v, tile, lane);
+        // Y again, from values the compiler cannot tell are the same: otherwise it would keep the
+        // first copy alive across the sort instead
+#pragma unroll
+        for (int r = 0; r < 64; r++) asm volatile("" : "+v"(w[r]));
+        w64_fwd_levels<NP, 5, false>(w, p, v, trow, a, b);
+        const double S = w64_gini_finish(v, rank, tile, lane);   // v = delta(:, lane)
 
         double gL[NP], gH[NP];
 #pragma unroll
         for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
-        w64_bwd_levels<NP, 0, true>(v, w, p, trow, a, b, gL, gH);   // columns; errors on Y1(:, lane) to the tile
-        w64_read_transposed(v, tile, lane);                         // v[c] = D1(lane, c): lane = row
-#pragma unroll
-        for (int c = 0; c < 64; c++) w[c] = Xe[lane + 64 * c];
-        w64_pyramid_levels<NP, 5>(w, p, a);
-        w64_bwd_levels<NP, 0, false>(v, w, p, trow, a, b, gL, gH);  // rows
+#ifndef W64_SKIP_BWD
+        w64_pyramid_to_tile<NP, 5>(w, p, trow, a);                // column pyramid into the lane's tile row
+        w64_bwd_levels<NP, 0, true>(v, w, trow, a, b, gL, gH);    // columns; errors on Y1(:, lane) to the tile
+        w64_read_transposed(v, tile, lane);                        // v[c] = D1(lane, c): lane = row
+        w64_load_rows(w, Xe, lane);
+        w64_pyramid_to_tile<NP, 5>(w, p, trow, a);
+        w64_bwd_levels<NP, 0, false>(v, w, trow, a, b, gL, gH);   // rows
+#endif
 
         // tap k' collects gL[k'] and sH[k'] gH[NP-1-k'], summed over the 64 lanes
         double mine = 0;
