@@ -179,14 +179,23 @@ __device__ __forceinline__ void w64_read_transposed(double (&v)[64], const doubl
 #pragma unroll
     for (int r = 0; r < 64; r++) v[r] = tile[r * 65 + lane];
 }
-// v[r] of lane l  ->  v[l] of lane r
+// v[r] of lane l  ->  v[l] of lane r.  The reads are issued in the order in which a compare-exchange
+// stage on register bit FIRST consumes them (r, r + 2^FIRST, ...), so that stage can start while
+// the rest is still in flight.
+template <int FIRST = 0>
 __device__ __forceinline__ void w64_transpose(double (&v)[64], double* tile, int lane) {
 #ifdef W64_SKIP_TRANSPOSE
     return;
 #endif
 #pragma unroll
     for (int r = 0; r < 64; r++) tile[lane * 65 + r] = v[r];
-    w64_read_transposed(v, tile, lane);
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        // i enumerates (pair, member): member bit goes to bit FIRST of r
+        const int pair = i >> 1, member = i & 1;
+        const int r = ((pair >> FIRST) << (FIRST + 1)) | (member << FIRST) | (pair & ((1 << FIRST) - 1));
+        v[r] = tile[r * 65 + lane];
+    }
 }
 
 // ---- sort ---------------------------------------------------------------------------------------------
@@ -232,14 +241,14 @@ __device__ __forceinline__ void w64_merge(double (&k)[64], double* tile, int lan
         w64_substages_down<5>(k);
     } else {
         // bits KK-1 .. 6 in layout B, then bits 5 .. 0 in layout A
-        w64_transpose(k, tile, lane);
+        w64_transpose<KK - 7>(k, tile, lane);
 #pragma unroll
         for (int r = 0; r < 64; r++) {
             const int hi = (KK < 12) ? ((r >> (KK - 6)) & 1) : 0, lo = (r >> (KK - 7)) & 1;
             if (hi ^ lo) flip_sign(k[r], SIGN);
         }
         w64_substages_down<KK - 7>(k);
-        w64_transpose(k, tile, lane);
+        w64_transpose<5>(k, tile, lane);
         w64_substages_down<5>(k);
     }
     if constexpr (KK < 12) w64_merge<KK + 1>(k, tile, lane);

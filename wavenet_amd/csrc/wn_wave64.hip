@@ -7,6 +7,7 @@ extern "C" const void* wn_kernel_wave64(int np) {
         case 2: return (const void*)&wn::k_train64<2>;
         case 4: return (const void*)&wn::k_train64<4>;
         case 8: return (const void*)&wn::k_train64<8>;
+        case 16: return (const void*)&wn::k_train64<16>;
     }
     return nullptr;
 }
