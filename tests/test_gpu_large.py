@@ -127,3 +127,52 @@ def test_full_size_properties_512(ctx):
     ex = (dX.view(B, n) ** 2).sum(dim=1)
     ey = (dY.view(B, n) ** 2).sum(dim=1)
     assert torch.allclose(ex, ey, rtol=1e-9)
+
+
+def _ctx_with_env(name, value):
+    import os
+    import torch
+    from wavenet_amd import Context
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        return Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    finally:
+        if old is None:
+            del os.environ[name]
+        else:
+            os.environ[name] = old
+
+
+@pytest.mark.parametrize("n,B", [(8192, 5), (65536, 3), (1 << 18, 2)])
+def test_sparse_term_32bit_keys_against_64bit_sort(ctx, oracle, n, B):
+    """The streamed Gini ranks with one sort of 32-bit keys (example number, leading magnitude bits) and
+    re-ranks groups of equal keys by exact magnitude and index.  Inputs: smooth random values (small
+    groups everywhere), zeros, and pairs that differ only in their last mantissa bits and stand in the
+    opposite order of their indices.  Yardsticks: the 64-bit sort of the same library and the oracle."""
+    import torch
+    rng = np.random.default_rng(n + B)
+    Y = rng.standard_normal((B, n)) * np.exp(rng.standard_normal((B, n)))
+    Y[0, ::7] = 0.0
+    base = 1.0 + rng.random(n // 8)
+    Y[1, 0:n // 8] = base * (1 + 2.0 ** -50)      # the larger one first ...
+    Y[1, n // 2:n // 2 + n // 8] = -base          # ... its near-twin later, with the other sign
+    Y[B - 1, 5::11] = Y[B - 1, 3::11][:len(Y[B - 1, 5::11])]   # exact ties
+    dY = torch.from_numpy(Y.reshape(-1)).cuda()
+    dD, dS = dev_empty(B * n), dev_empty(B)
+    ctx.sparse_term_deriv(dY, B, n, dD, dS)
+    torch.cuda.synchronize()
+    D, S = dD.cpu().numpy().reshape(B, n), dS.cpu().numpy()
+    exact = _ctx_with_env("WAVENET_HIP_EXACT_SORT", "1")
+    try:
+        dD2, dS2 = dev_empty(B * n), dev_empty(B)
+        exact.sparse_term_deriv(dY, B, n, dD2, dS2)
+        torch.cuda.synchronize()
+        D2, S2 = dD2.cpu().numpy().reshape(B, n), dS2.cpu().numpy()
+    finally:
+        exact.close()
+    assert np.abs(S - S2).max() < 1e-13
+    for e in range(B):
+        assert relerr(D[e], D2[e]) < 1e-12
+        assert S[e] == pytest.approx(oracle.sparse_term(Y[e]), rel=1e-11)
+        assert relerr(D[e], oracle.sparse_term_deriv(Y[e])) < 1e-10

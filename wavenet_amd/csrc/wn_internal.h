@@ -22,6 +22,7 @@ struct wn_context {
     int N = 0, NP = 0;
     double* partial = nullptr;
     int partial_blocks = 0;
+    bool exact_sort = false;  // streamed path: always the 64-bit sort (WAVENET_HIP_EXACT_SORT=1; for tests)
     bool wave64 = true;  // 64x64 training on the one-wave-per-example kernel (WAVENET_HIP_WAVE64=0 turns it off)
     double* sums = nullptr;
     double* own_sums = nullptr;

@@ -230,6 +230,117 @@ __global__ __launch_bounds__(BT) void kb_gini_delta(const unsigned* pos, const d
     }
 }
 
+// ---- Gini, fast path: 32-bit keys ------------------------------------------------------------------
+// One radix sort of 32-bit keys instead of a 64-bit and a segment sort: key = example number in the top
+// bits, then as many leading bits of the magnitude (exponent first) as fit.  Positions whose keys are
+// equal form a group -- same example, magnitudes equal in those leading bits -- that the stable sort
+// leaves in index order; kb_fix_ranks puts each group in (exact magnitude, index) order by counting.
+// Groups of exact zeros need no order (rank times sign(0) is 0).  A group longer than GROUP_LIMIT
+// would make the counting quadratic: kb_gather_sorted notices and the caller takes the 64-bit path.
+constexpr unsigned GROUP_LIMIT = 1024;
+
+__global__ void kb_key32(const double* Y, unsigned* key, unsigned* idx, size_t total, int lgn, int magbits) {
+    for (size_t i = (size_t)blockIdx.x * BT + threadIdx.x; i < total; i += (size_t)gridDim.x * BT) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(Y[i]) & 0x7FFFFFFFFFFFFFFFull;
+        const unsigned ex = (unsigned)(i >> lgn);
+        key[i] = (magbits < 32 ? (ex << magbits) : 0u) | (unsigned)(bits >> (63 - magbits));
+        idx[i] = (unsigned)i;
+    }
+}
+// F[p] = coefficient at sorted position p; *flag set when a group of non-zero keys is too long
+__global__ void kb_gather_sorted(const double* Y, const unsigned* key, const unsigned* idx, double* F, size_t total,
+                                 unsigned magmask, unsigned* flag) {
+    bool over = false;
+    for (size_t p = (size_t)blockIdx.x * BT + threadIdx.x; p < total; p += (size_t)gridDim.x * BT) {
+        F[p] = Y[idx[p]];
+        const unsigned k = key[p];
+        if ((k & magmask) != 0 && p + GROUP_LIMIT < total && key[p + GROUP_LIMIT] == k) over = true;
+    }
+    if (over) *flag = 1u;
+}
+// rank[p] (1-based, within the example) of the element at sorted position p, and the example's partial
+// sums: part[(example * GXMAX + workgroup) * 2 + {0,1}] = partial f, partial sum |c|.  grid (GXMAX, B).
+// The workgroup stages tiles of FIX_TILE positions plus FIX_HALO on either side in LDS; a group that
+// reaches past the staged range (rare) is counted from global memory instead.
+constexpr int FIX_TILE = 2048, FIX_HALO = 32;
+__global__ __launch_bounds__(BT) void kb_fix_ranks(const unsigned* key, const unsigned* idx, const double* F, unsigned n,
+                                                   unsigned magmask, unsigned* rank, double* part) {
+    __shared__ double red[2 * (BT / 64)];
+    __shared__ double la[FIX_TILE + 2 * FIX_HALO];
+    __shared__ unsigned lk[FIX_TILE + 2 * FIX_HALO], li[FIX_TILE + 2 * FIX_HALO];
+    const size_t exstart = (size_t)blockIdx.y * n, exend = exstart + n;
+    const unsigned span = n / gridDim.x;   // a multiple of FIX_TILE or a power of two below it
+    const size_t p0 = exstart + (size_t)blockIdx.x * span;
+    const unsigned tile = span < (unsigned)FIX_TILE ? span : (unsigned)FIX_TILE;
+    const int tid = threadIdx.x;
+    double f = 0, a = 0;
+    for (size_t t0 = p0; t0 < p0 + span; t0 += tile) {
+        const size_t lo = (t0 >= exstart + FIX_HALO) ? t0 - FIX_HALO : exstart;
+        const size_t hi = (t0 + tile + FIX_HALO <= exend) ? t0 + tile + FIX_HALO : exend;
+        const int cnt = (int)(hi - lo);
+        __syncthreads();
+        for (int l = tid; l < cnt; l += BT) {
+            lk[l] = key[lo + l];
+            la[l] = __builtin_fabs(F[lo + l]);
+            li[l] = idx[lo + l];
+        }
+        __syncthreads();
+        for (size_t p = t0 + tid; p < t0 + tile; p += BT) {
+            const int l = (int)(p - lo);
+            const unsigned k = lk[l];
+            const double av = la[l];
+            unsigned rk = (unsigned)(p - exstart) + 1u;
+            if ((k & magmask) == 0 && av == 0.0) {
+                rk = 0;  // never used: the sign of a zero is zero
+            } else if ((l > 0 && lk[l - 1] == k) || (l + 1 < cnt && lk[l + 1] == k)) {
+                int gs = l;
+                while (gs > 0 && lk[gs - 1] == k) gs--;
+                int ge = l + 1;
+                while (ge < cnt && lk[ge] == k) ge++;
+                const unsigned me = li[l];
+                unsigned below = 0;
+                if ((gs > 0 || lo == exstart) && (ge < cnt || hi == exend)) {
+                    for (int q = gs; q < ge; q++) below += (la[q] < av || (la[q] == av && li[q] < me)) ? 1u : 0u;
+                    rk = (unsigned)(lo + gs - exstart) + below + 1u;
+                } else {  // the group reaches past the staged range
+                    size_t g0 = p;
+                    while (g0 > exstart && key[g0 - 1] == k) g0--;
+                    for (size_t q = g0; q < exend && key[q] == k; q++) {
+                        const double aq = __builtin_fabs(F[q]);
+                        below += (aq < av || (aq == av && idx[q] < me)) ? 1u : 0u;
+                    }
+                    rk = (unsigned)(g0 - exstart) + below + 1u;
+                }
+            }
+            rank[p] = rk;
+            f = __builtin_fma(2.0 * (double)rk - (double)n - 1.0, av, f);
+            a += av;
+        }
+    }
+    f = wave_sum(f);
+    a = wave_sum(a);
+    __syncthreads();
+    if ((tid & 63) == 0) { red[tid >> 6] = f; red[BT / 64 + (tid >> 6)] = a; }
+    __syncthreads();
+    if (tid < 2) {
+        double t = 0;
+        for (int wv = 0; wv < BT / 64; wv++) t += red[tid * (BT / 64) + wv];
+        part[((size_t)blockIdx.y * GXMAX + blockIdx.x) * 2 + tid] = t;
+    }
+}
+// delta of the element at sorted position p, written to its home
+__global__ __launch_bounds__(BT) void kb_delta_scatter(const unsigned* rank, const unsigned* idx, const double* F, double* Dout,
+                                                       const double* fg, unsigned n) {
+    const size_t off = (size_t)blockIdx.y * n;
+    const double f = fg[2 * blockIdx.y], g = fg[2 * blockIdx.y + 1];
+    const double inv_g2 = 1.0 / (g * g);
+    for (unsigned p = blockIdx.x * BT + threadIdx.x; p < n; p += gridDim.x * BT) {
+        const double sg = sign_ref(F[off + p]);
+        const double df = (2.0 * (double)rank[off + p] - (double)n - 1.0) * sg;
+        Dout[idx[off + p]] = -(df * g - f * ((double)n * sg)) * inv_g2;
+    }
+}
+
 // ---- workspace ----------------------------------------------------------------------------------------
 struct Carver {
     char* base;
@@ -337,6 +448,57 @@ int gini_big(wn_context* ctx, const double* Y, double* D, int B, size_t n, doubl
     return WN_OK;
 }
 
+// Gini term and gradient of a chunk: the 32-bit-key path when it applies, else gini_big.  The chunk is
+// sorted in slices of few enough examples that the example number leaves about lg(n) - 2 mantissa
+// bits in the key: groups of equal keys then hold about one element on smooth data.
+int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB,
+               unsigned* idxA, unsigned* idxB, double* gpart, double* fg, double* S_e, void* sort_tmp,
+               size_t sort_tmp_bytes) {
+    int lgn = 0;
+    while (((size_t)1 << lgn) < n) lgn++;
+    const int exbits_max = 23 - lgn;   // 32 - exbits >= 11 exponent bits + (lgn - 2) mantissa bits
+    if (exbits_max < 0 || ctx->exact_sort)
+        return gini_big(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, gpart, fg, S_e, sort_tmp, sort_tmp_bytes);
+    const int slice = std::min(B, 1 << exbits_max);
+    int exbits = 0;
+    while ((1 << exbits) < slice) exbits++;
+    const int magbits = 32 - exbits;
+    const unsigned magmask = magbits >= 32 ? 0xFFFFFFFFu : ((1u << magbits) - 1u);
+    hipStream_t st = ctx->stream;
+    unsigned* flag = idxA;   // the first slice's idxA is free once its sort has run
+    for (int e0 = 0; e0 < B; e0 += slice) {
+        const int Bs = std::min(slice, B - e0);
+        const size_t off = (size_t)e0 * n, total = (size_t)Bs * n;
+        const unsigned blocks = (unsigned)std::min<size_t>((total + BT - 1) / BT, 65536);
+        unsigned* keyA = reinterpret_cast<unsigned*>(keysA + off);   // two 32-bit arrays in the slice of keysA
+        unsigned* keyB = keyA + total;
+        hipLaunchKernelGGL(kb_key32, dim3(blocks), dim3(BT), 0, st, Y + off, keyA, idxA + off, total, lgn, magbits);
+        WN_HIP(ctx, rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keyA, keyB, idxA + off, idxB + off, total, 0, 32, st));
+        if (e0 == 0) WN_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(unsigned), st));
+        hipLaunchKernelGGL(kb_gather_sorted, dim3(blocks), dim3(BT), 0, st, Y + off, keyB, idxB + off, keysB + off, total, magmask, flag);
+    }
+    unsigned over = 0;
+    WN_HIP(ctx, hipMemcpyAsync(&over, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    WN_HIP(ctx, hipStreamSynchronize(st));
+    if (over) return gini_big(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, gpart, fg, S_e, sort_tmp, sort_tmp_bytes);
+    const int gx = (int)std::min<size_t>(n / BT, GXMAX);   // n is a power of two >= 8192: gx divides it
+    for (int e0 = 0; e0 < B; e0 += slice) {
+        const int Bs = std::min(slice, B - e0);
+        const size_t off = (size_t)e0 * n, total = (size_t)Bs * n;
+        unsigned* keyA = reinterpret_cast<unsigned*>(keysA + off);
+        unsigned* keyB = keyA + total;
+        unsigned* rank = keyA;
+        hipLaunchKernelGGL(kb_fix_ranks, dim3(gx, Bs), dim3(BT), 0, st, keyB, idxB + off, keysB + off, (unsigned)n, magmask, rank,
+                           gpart + (size_t)e0 * GXMAX * 2);
+        hipLaunchKernelGGL(kb_gini_finish, dim3((Bs + BT - 1) / BT), dim3(BT), 0, st, gpart + (size_t)e0 * GXMAX * 2, Bs, gx,
+                           (unsigned)n, fg + 2 * (size_t)e0, S_e ? S_e + e0 : nullptr);
+        if (D) hipLaunchKernelGGL(kb_delta_scatter, grid_for((int)std::min<size_t>(n, 1u << 30), Bs), dim3(BT), 0, st, rank,
+                                  idxB + off, keysB + off, D + off, fg + 2 * (size_t)e0, (unsigned)n);
+    }
+    WN_HIP(ctx, hipGetLastError());
+    return WN_OK;
+}
+
 size_t sort_temp_bytes(size_t total) {
     size_t a = 0, b = 0;
     (void)rocprim::radix_sort_pairs(nullptr, a, (double*)nullptr, (double*)nullptr, (unsigned*)nullptr,
@@ -414,7 +576,7 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         if (forward_only) continue;
         double* S_e = S ? S + e0 : pl.S_e;
         double* grad_e = grad ? grad + (size_t)e0 * N : pl.grad_e;
-        if ((rc = gini_big(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes))) return rc;
+        if ((rc = gini_large(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes))) return rc;
         WN_HIP(ctx, hipMemsetAsync(pl.partial, 0, (size_t)Bc * GXMAX * 2 * NP * sizeof(double), st));
         const double* D1 = nullptr;
         if ((rc = bwd_pass_big<NP>(ctx, YD, Y1, Pcol, pl.A, pl.Bb, Bc, n, cg, lgC > 0, pl.partial, &D1))) return rc;
@@ -515,7 +677,7 @@ int large_sparse(wn_context* ctx, const double* Y, int B, long long n, double* D
     for (int e0 = 0; e0 < B; e0 += pl.Bc) {
         const int Bc = std::min(pl.Bc, B - e0);
         const size_t o = (size_t)e0 * n;
-        if ((rc = gini_big(ctx, Y + o, Delta ? Delta + o : nullptr, Bc, (size_t)n, pl.A, pl.Bb, pl.idxA, pl.idxB,
+        if ((rc = gini_large(ctx, Y + o, Delta ? Delta + o : nullptr, Bc, (size_t)n, pl.A, pl.Bb, pl.idxA, pl.idxB,
                            pl.gpart, pl.fg, S ? S + e0 : nullptr, pl.sort_tmp, pl.sort_tmp_bytes)))
             return rc;
     }
