@@ -180,8 +180,9 @@ int wn_clear_logs(wn_context* ctx);
 /* ---- measurement --------------------------------------------------------------------------- */
 /*
  * Brackets the training kernel of every following wn_train_batch with a pair of HIP events on
- * the context's stream (at most max_records launches; 0 turns it off).  wn_profile_collect
- * synchronises and returns the kernel durations in milliseconds, oldest first.
+ * the context's stream (at most max_records launches; 0 turns it off).  For examples that take the
+ * streamed path the pair spans all of its kernels.  wn_profile_collect synchronises and returns the
+ * durations in milliseconds, oldest first.
  */
 int wn_profile_begin(wn_context* ctx, int max_records);
 int wn_profile_collect(wn_context* ctx, float* ms_host, int capacity, int* count);

@@ -34,7 +34,7 @@ namespace {
 enum { KIND_TRAIN = 0, KIND_FORWARD = 1, KIND_INVERSE = 2, KIND_BACKPROP = 3 };
 
 struct SizeClass { int T, Q, NS; };
-const SizeClass kSizeClasses[5] = {{64, 1, 128}, {64, 3, 512}, {128, 3, 1024}, {256, 3, 2048}, {512, 3, 4096}};
+const SizeClass kSizeClasses[5] = {{64, 1, 128}, {64, 3, 512}, {64, 4, 1024}, {256, 3, 2048}, {512, 3, 4096}};
 const int kLogCap = 16384;
 
 }  // namespace
@@ -534,7 +534,18 @@ int wn_train_batch(wn_context* ctx, const double* X, int B, int R, int C, double
     int rc = check_shape(ctx, B, R, C, true, &lgR, &lgC, &sc);
     if (rc) return rc;
     if (B > 0 && !X) return fail(ctx, WN_ERR_ARG, "null input");
-    if (sc < 0 && B > 0) return wn::large_train(ctx, X, B, lgR, lgC, grad, Sout);
+    if (sc < 0 && B > 0) {
+        // streamed path: the profiling record spans all of its kernels
+        const bool prof = ctx->prof_used < (int)ctx->prof_begin.size();
+        if (prof) WN_HIP(ctx, hipEventRecord(ctx->prof_begin[ctx->prof_used], ctx->stream));
+        rc = wn::large_train(ctx, X, B, lgR, lgC, grad, Sout);
+        if (rc) return rc;
+        if (prof) {
+            WN_HIP(ctx, hipEventRecord(ctx->prof_end[ctx->prof_used], ctx->stream));
+            ctx->prof_used++;
+        }
+        return WN_OK;
+    }
     const SizeClass& S = kSizeClasses[sc < 0 ? 0 : sc];
     wn::FusedArgs A;
     memset(&A, 0, sizeof(A));

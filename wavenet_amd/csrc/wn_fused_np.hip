@@ -23,7 +23,7 @@ extern "C" const void* WN_CAT(wn_kernel_np, WN_NP)(int kind, int sc) {
     switch (sc) {
         case 0: { WN_KERNELS(64, 1) }
         case 1: { WN_KERNELS(64, 3) }
-        case 2: { WN_KERNELS(128, 3) }
+        case 2: { WN_KERNELS(64, 4) }
         case 3: { WN_KERNELS(256, 3) }
         case 4: { WN_KERNELS(512, 3) }
     }
