@@ -18,7 +18,6 @@
 #include "wn_costfn.h"
 #include "wn_internal.h"
 #include "wn_kernels.h"
-#include "wn_wave64.h"
 
 // kernel tables, one translation unit per compiled tap count (wn_fused_np.hip)
 extern "C" const void* wn_kernel_np2(int kind, int sc);
@@ -27,6 +26,8 @@ extern "C" const void* wn_kernel_np8(int kind, int sc);
 extern "C" const void* wn_kernel_np16(int kind, int sc);
 extern "C" const void* wn_kernel_np32(int kind, int sc);
 extern "C" const void* wn_kernel_wave64(int np);
+extern "C" const void* wn_kernel_wave64_transform(int kind, int np);
+extern "C" const void* wn_kernel_wave64_sparse();
 extern "C" const void* wn_kernel_sparse(int sc);
 
 namespace {
@@ -448,6 +449,8 @@ int wn_forward(wn_context* ctx, const double* X, int B, int R, int C, double* Y,
     memset(&A, 0, sizeof(A));
     A.B = B; A.lgR = lgR; A.lgC = lgC; A.filt = ctx->dfilt;
     A.X = X; A.Y = Y; A.Prow = Prow; A.Y1 = Y1; A.Pcol = Pcol;
+    if (const void* w64 = (lgR == 6 && lgC == 6 && ctx->wave64) ? wn_kernel_wave64_transform(KIND_FORWARD, ctx->NP) : nullptr)
+        return launch(ctx, w64, 256, (size_t)4 * wn::W64_TILE * sizeof(double), (B + 3) / 4, A, nullptr);
     const size_t shmem = (size_t)4 * R * C * sizeof(double);
     return launch(ctx, fused_kernel(ctx->NP, KIND_FORWARD, sc), S.T, shmem, B, A, nullptr);
 }
@@ -464,6 +467,8 @@ int wn_inverse(wn_context* ctx, const double* Y, int B, int R, int C, double* X)
     memset(&A, 0, sizeof(A));
     A.B = B; A.lgR = lgR; A.lgC = lgC; A.filt = ctx->dfilt;
     A.Yin = Y; A.Xout = X;
+    if (const void* w64 = (lgR == 6 && lgC == 6 && ctx->wave64) ? wn_kernel_wave64_transform(KIND_INVERSE, ctx->NP) : nullptr)
+        return launch(ctx, w64, 256, (size_t)4 * wn::W64_TILE * sizeof(double), (B + 3) / 4, A, nullptr);
     const size_t shmem = (size_t)R * C * sizeof(double) + 16;
     return launch(ctx, fused_kernel(ctx->NP, KIND_INVERSE, sc), S.T, shmem, B, A, nullptr);
 }
@@ -481,6 +486,8 @@ int wn_backprop(wn_context* ctx, const double* Delta, const double* X, const dou
     memset(&A, 0, sizeof(A));
     A.B = B; A.lgR = lgR; A.lgC = lgC; A.filt = ctx->dfilt;
     A.Din = Delta; A.X = X; A.ProwIn = Prow; A.Y1In = Y1; A.PcolIn = Pcol; A.grad = grad; A.Delta = din;
+    if (const void* w64 = (lgR == 6 && lgC == 6 && ctx->wave64) ? wn_kernel_wave64_transform(KIND_BACKPROP, ctx->NP) : nullptr)
+        return launch(ctx, w64, 256, (size_t)4 * wn::W64_TILE * sizeof(double), (B + 3) / 4, A, nullptr);
     const size_t shmem = ((size_t)4 * R * C + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double);
     return launch(ctx, fused_kernel(ctx->NP, KIND_BACKPROP, sc), S.T, shmem, B, A, nullptr);
 }
@@ -502,6 +509,8 @@ int wn_sparse_term_deriv(wn_context* ctx, const double* Y, int B, int n, double*
     memset(&A, 0, sizeof(A));
     A.B = B; A.lgR = lgn; A.lgC = 0;
     A.Yin = Y; A.Delta = Delta; A.S = Sout;
+    if (n == 4096 && ctx->wave64)
+        return launch(ctx, wn_kernel_wave64_sparse(), 256, (size_t)4 * wn::W64_TILE * sizeof(double), (B + 3) / 4, A, nullptr);
     const size_t shmem = ((size_t)S.NS + S.T / 64 + 2) * sizeof(double) + 16;
     return launch(ctx, wn_kernel_sparse(sc), S.T, shmem, B, A, nullptr);
 }

@@ -8,6 +8,7 @@
 namespace wn {
 
 constexpr int PSTRIDE = MAXTAPS + 2;  // doubles per workgroup in the partial-sum buffer
+constexpr int W64_TILE = 64 * 65;     // doubles of LDS per wave in the one-wave-per-example kernels (wn_wave64.h)
 
 struct FusedArgs {
     int B, lgR, lgC;

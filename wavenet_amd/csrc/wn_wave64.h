@@ -21,7 +21,6 @@
 
 namespace wn {
 
-constexpr int W64_TILE = 64 * 65;  // doubles of LDS per wave
 
 // min -> lo, max -> hi.  Plain (not volatile) asm: two instructions, free to be scheduled.
 __device__ __forceinline__ void cmpx_asm(double& lo, double& hi) {
@@ -110,39 +109,45 @@ __device__ __forceinline__ void w64_pyramid_to_tile(const double (&x)[64], doubl
     if constexpr (LG > 1) w64_pyramid_to_tile<NP, LG - 1>(x, p, trow, a);
 }
 
-// Backward cascade of a line, levels LG = 0..5 (src/Wavenet.cxx:509-545): d in place.  The
-// activations below the top level come from the lane's row of the LDS tile (w64_pyramid_to_tile).
-// At the top level the errors on the line's input are either not needed (TOP_TO_TILE false: row
-// stage) or go straight to that row (column stage: first half of the transpose) -- after the last
-// read of the pyramid, which the in-order LDS keeps safe.
-template <int NP, int LG, bool TOP_TO_TILE>
+// Backward cascade of a line, levels LG = 0..5 (src/Wavenet.cxx:509-545): d in place.  With GRAD the
+// filter-gradient correlation is accumulated, its activations below the top level coming from the
+// lane's row of the LDS tile (w64_pyramid_to_tile); without it this is the inverse transform of the
+// line (src/Wavenet.cxx:447-472) and x, the tile row and gL / gH are not touched.  At the top level
+// the errors on the line's input (the reconstructed line) are dropped (TOP = W64_TOP_NONE: row stage
+// of the training step), go straight to the lane's tile row (W64_TOP_TILE: first half of a transpose;
+// after the last read of the pyramid, which the in-order LDS keeps safe) or replace d (W64_TOP_REGS).
+constexpr int W64_TOP_NONE = 0, W64_TOP_TILE = 1, W64_TOP_REGS = 2;
+template <int NP, int LG, int TOP, bool GRAD>
 __device__ __forceinline__ void w64_bwd_levels(double (&d)[64], const double (&x)[64], double* trow,
                                                const double (&a)[NP], const double (&b)[NP],
                                                double (&gL)[NP], double (&gH)[NP]) {
     constexpr int len = 1 << LG, alen = 2 * len;
-    double act[LG < 5 ? alen : 1];
-    if constexpr (LG < 5) {
+    if constexpr (GRAD) {
+        double act[LG < 5 ? alen : 1];
+        if constexpr (LG < 5) {
 #pragma unroll
-        for (int i = 0; i < alen; i++) act[i] = trow[alen + i];
-    }
+            for (int i = 0; i < alen; i++) act[i] = trow[alen + i];
+        }
 #pragma unroll
-    for (int r = 0; r < len; r++) {
-        const double dl = d[r], dh = d[len + r];
+        for (int r = 0; r < len; r++) {
+            const double dl = d[r], dh = d[len + r];
 #pragma unroll
-        for (int u = 0; u < NP; u++) {
-            const int idx = (2 * r + NP / 2 - u) & (alen - 1);
-            double v;
-            if constexpr (LG == 5) v = x[idx];
-            else v = act[idx];
-            gL[u] = __builtin_fma(dl, v, gL[u]);
-            gH[u] = __builtin_fma(dh, v, gH[u]);
+            for (int u = 0; u < NP; u++) {
+                const int idx = (2 * r + NP / 2 - u) & (alen - 1);
+                double v;
+                if constexpr (LG == 5) v = x[idx];
+                else v = act[idx];
+                gL[u] = __builtin_fma(dl, v, gL[u]);
+                gH[u] = __builtin_fma(dh, v, gH[u]);
+            }
         }
     }
-    if constexpr (LG < 5 || TOP_TO_TILE) {
+    if constexpr (LG < 5 || TOP != W64_TOP_NONE) {
         constexpr int S = NP / 2;
         constexpr int JE = S & 1, JO = (S + 1) & 1;
         constexpr int CE = (JE - S) / 2, CO = (1 + JO - S) / 2;
-        double nw[LG < 5 ? alen : 2];
+        constexpr bool to_tile = (LG == 5 && TOP == W64_TOP_TILE);
+        double nw[to_tile ? 2 : alen];
 #pragma unroll
         for (int q = 0; q < len; q++) {
             double se = 0, so = 0;
@@ -154,20 +159,20 @@ __device__ __forceinline__ void w64_bwd_levels(double (&d)[64], const double (&x
                 so = __builtin_fma(a[JO + 2 * i], d[ro], so);
                 so = __builtin_fma(b[JO + 2 * i], d[len + ro], so);
             }
-            if constexpr (LG < 5) {
-                nw[2 * q] = se;
-                nw[2 * q + 1] = so;
-            } else {
+            if constexpr (to_tile) {
                 trow[2 * q] = se;
                 trow[2 * q + 1] = so;
+            } else {
+                nw[2 * q] = se;
+                nw[2 * q + 1] = so;
             }
         }
-        if constexpr (LG < 5) {
+        if constexpr (!to_tile) {
 #pragma unroll
             for (int c = 0; c < alen; c++) d[c] = nw[c];
         }
     }
-    if constexpr (LG < 5) w64_bwd_levels<NP, LG + 1, TOP_TO_TILE>(d, x, trow, a, b, gL, gH);
+    if constexpr (LG < 5) w64_bwd_levels<NP, LG + 1, TOP, GRAD>(d, x, trow, a, b, gL, gH);
 }
 
 // ---- 64x64 transpose through the wave's LDS tile -----------------------------------------------------
@@ -476,6 +481,166 @@ __device__ __forceinline__ void w64_load_rows(double (&v)[64], const double* Xe,
     }
 }
 
+
+// One example row-wise back to memory: X(lane, c) = v[c].  Same addressing as w64_load_rows.
+__device__ __forceinline__ void w64_store_rows(const double (&v)[64], double* Xe, int lane) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        typedef __attribute__((address_space(1))) double* global_ptr;
+        global_ptr bj = (global_ptr)(Xe + 512 * j);
+        asm volatile("" : "+s"(bj));
+#pragma unroll
+        for (int c = 0; c < 8; c++) bj[lane + 64 * c] = v[8 * j + c];
+    }
+}
+
+// Forward transform of 64x64 examples (Wavenet::forward_, src/Wavenet.cxx:562-622), one wave per example.
+// Everything leaves in row orientation (lane = row), so that every store instruction covers 512
+// consecutive bytes; the column-stage results take one more trip through the tile for that.
+template <int NP>
+__global__ __launch_bounds__(256, 1) void k_forward64(FusedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const FilterDev* filt = A.filt;
+    double a[NP], b[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    const int nslots = gridDim.x * 4;
+    for (int e = blockIdx.x * 4 + wave; e < A.B; e += nslots) {
+        const size_t off = (size_t)e * 4096;
+        unsigned tile_off = (unsigned)wave * W64_TILE;
+        asm volatile("" : "+s"(tile_off));
+        double* tile = smem + tile_off;
+        double* trow = tile + lane * 65;
+        double v[64], w[64], p[64];
+        w64_load_rows(v, A.X + off, lane);
+        w64_fwd_levels<NP, 5, false>(v, p, w, trow, a, b);       // w = Y1(lane, :), p = row pyramid
+        p[0] = 0;
+        if (A.Prow) w64_store_rows(p, A.Prow + off, lane);
+        if (A.Y1) w64_store_rows(w, A.Y1 + off, lane);
+#pragma unroll
+        for (int c = 0; c < 64; c++) trow[c] = w[c];
+        w64_read_transposed(w, tile, lane);                       // w[r] = Y1(r, lane)
+        w64_fwd_levels<NP, 5, false>(w, p, v, trow, a, b);       // v = Y(:, lane), p = column pyramid
+        p[0] = 0;
+        if (A.Y) {
+            w64_transpose(v, tile, lane);                         // v[c] = Y(lane, c)
+            w64_store_rows(v, A.Y + off, lane);
+        }
+        if (A.Pcol) {
+            w64_transpose(p, tile, lane);
+            w64_store_rows(p, A.Pcol + off, lane);
+        }
+    }
+}
+
+// Inverse transform of 64x64 examples (Wavenet::inverse_, src/Wavenet.cxx:624-663): columns, then rows.
+template <int NP>
+__global__ __launch_bounds__(256, 1) void k_inverse64(FusedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const FilterDev* filt = A.filt;
+    double a[NP], b[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    double gL[NP], gH[NP];   // not used without the gradient
+    const int nslots = gridDim.x * 4;
+    for (int e = blockIdx.x * 4 + wave; e < A.B; e += nslots) {
+        const size_t off = (size_t)e * 4096;
+        unsigned tile_off = (unsigned)wave * W64_TILE;
+        asm volatile("" : "+s"(tile_off));
+        double* tile = smem + tile_off;
+        double* trow = tile + lane * 65;
+        double v[64];
+        w64_load_rows(v, A.Yin + off, lane);                      // v[c] = Y(lane, c)
+        w64_transpose(v, tile, lane);                             // v[r] = Y(r, lane): lane = column
+        w64_bwd_levels<NP, 0, W64_TOP_TILE, false>(v, v, trow, a, b, gL, gH);   // columns, result to the tile
+        w64_read_transposed(v, tile, lane);                       // v[c] = Y1(lane, c): lane = row
+        w64_bwd_levels<NP, 0, W64_TOP_REGS, false>(v, v, trow, a, b, gL, gH);   // rows
+        w64_store_rows(v, A.Xout + off, lane);
+    }
+}
+
+
+// SparseTerm / SparseTermDeriv (src/CostFunctions.cxx:6-117) on sets of 4096 coefficients, one wave per set.
+__global__ __launch_bounds__(256, 1) void k_sparse64(FusedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nslots = gridDim.x * 4;
+    for (int e = blockIdx.x * 4 + wave; e < A.B; e += nslots) {
+        const size_t off = (size_t)e * 4096;
+        unsigned tile_off = (unsigned)wave * W64_TILE;
+        asm volatile("" : "+s"(tile_off));
+        double* tile = smem + tile_off;
+        double v[64];
+        w64_load_rows(v, A.Yin + off, lane);
+        w64_transpose(v, tile, lane);                 // v[r] = element r + 64 * lane
+        const W64Rank rank = w64_rank_sort(v, tile, lane);
+        const double S = w64_gini_finish(v, rank, tile, lane);
+        if (A.Delta) {
+            w64_transpose(v, tile, lane);
+            w64_store_rows(v, A.Delta + off, lane);
+        }
+        if (A.S && lane == 0) A.S[e] = S;
+    }
+}
+
+// Backpropagation of 64x64 examples from given errors and activations (Wavenet::backpropagate_,
+// src/Wavenet.cxx:665-711).  Delta (optional) receives the errors after the column stage.
+template <int NP>
+__global__ __launch_bounds__(256, 1) void k_backprop64(FusedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const FilterDev* filt = A.filt;
+    double a[NP], b[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    const int N = filt->N, dpad = filt->d;
+    const int nslots = gridDim.x * 4;
+    for (int e = blockIdx.x * 4 + wave; e < A.B; e += nslots) {
+        const size_t off = (size_t)e * 4096;
+        unsigned tile_off = (unsigned)wave * W64_TILE;
+        asm volatile("" : "+s"(tile_off));
+        double* tile = smem + tile_off;
+        double* trow = tile + lane * 65;
+        double v[64], w[64];
+        w64_load_rows(v, A.Din + off, lane);
+        w64_transpose(v, tile, lane);                 // v[r] = errors on Y(r, lane)
+        w64_load_rows(w, A.Y1In + off, lane);
+        w64_transpose(w, tile, lane);                 // w[r] = Y1(r, lane)
+        {   // column pyramid, given row-wise, into the tile rows of its columns
+            double p[64];
+            w64_load_rows(p, A.PcolIn + off, lane);
+#pragma unroll
+            for (int c = 0; c < 64; c++) tile[c * 65 + lane] = p[c];
+        }
+        double gL[NP], gH[NP];
+#pragma unroll
+        for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
+        w64_bwd_levels<NP, 0, W64_TOP_TILE, true>(v, w, trow, a, b, gL, gH);
+        w64_read_transposed(v, tile, lane);           // v[c] = errors on Y1(lane, c)
+        if (A.Delta) w64_store_rows(v, A.Delta + off, lane);
+        w64_load_rows(w, A.X + off, lane);
+        {
+            double p[64];
+            w64_load_rows(p, A.ProwIn + off, lane);
+#pragma unroll
+            for (int c = 0; c < 64; c++) trow[c] = p[c];
+        }
+        w64_bwd_levels<NP, 0, W64_TOP_NONE, true>(v, w, trow, a, b, gL, gH);
+        double mine = 0;
+#pragma unroll
+        for (int kp = 0; kp < NP; kp++) {
+            double c = filt->vL[kp] * gL[kp] + filt->sH[kp] * gH[NP - 1 - kp];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            if (lane == kp) mine = c;
+        }
+        const int k = lane - dpad;
+        if (lane < NP && k >= 0 && k < N) A.grad[(size_t)e * N + k] = mine;
+    }
+}
+
 // ---- kernel ---------------------------------------------------------------------------------------------
 // 256 threads = 4 waves = 4 examples in flight per workgroup; grid-stride over the batch.
 template <int NP>
@@ -519,11 +684,11 @@ __global__ __launch_bounds__(256, 1) void k_train64(FusedArgs A) {
         for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
 #ifndef W64_SKIP_BWD
         w64_pyramid_to_tile<NP, 5>(w, p, trow, a);                // column pyramid into the lane's tile row
-        w64_bwd_levels<NP, 0, true>(v, w, trow, a, b, gL, gH);    // columns; errors on Y1(:, lane) to the tile
+        w64_bwd_levels<NP, 0, W64_TOP_TILE, true>(v, w, trow, a, b, gL, gH);    // columns; errors on Y1(:, lane) to the tile
         w64_read_transposed(v, tile, lane);                        // v[c] = D1(lane, c): lane = row
         w64_load_rows(w, Xe, lane);
         w64_pyramid_to_tile<NP, 5>(w, p, trow, a);
-        w64_bwd_levels<NP, 0, false>(v, w, trow, a, b, gL, gH);   // rows
+        w64_bwd_levels<NP, 0, W64_TOP_NONE, true>(v, w, trow, a, b, gL, gH);   // rows
 #endif
 
         // tap k' collects gL[k'] and sH[k'] gH[NP-1-k'], summed over the 64 lanes
