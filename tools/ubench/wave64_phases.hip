@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, 1) void k_phases(FusedArgs A, long long* phase
         }
 #endif
         w64_pyramid_to_tile<NP, 5>(w, p, trow, a);
-        w64_bwd_levels<NP, 0, true>(v, w, trow, a, b, gL, gH);
+        w64_bwd_levels<NP, 0, W64_TOP_TILE, true>(v, w, trow, a, b, gL, gH);
         TICK(6)
         w64_read_transposed(v, tile, lane);
 #ifndef H_SKIP_RELOAD
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, 1) void k_phases(FusedArgs A, long long* phase
 #endif
         TICK(7)
         w64_pyramid_to_tile<NP, 5>(w, p, trow, a);
-        w64_bwd_levels<NP, 0, false>(v, w, trow, a, b, gL, gH);
+        w64_bwd_levels<NP, 0, W64_TOP_NONE, true>(v, w, trow, a, b, gL, gH);
         TICK(8)
         double mine = S;
 #pragma unroll
