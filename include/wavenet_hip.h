@@ -56,8 +56,8 @@ typedef struct wn_context wn_context;
 
 /* ---- context ---------------------------------------------------------------------------- */
 /* One context per device and caller thread.  Environment read here: WAVENET_HIP_WAVE64=0 keeps the
- * training of 64x64 examples on the workgroup-per-example kernel (the default for that shape, up to
- * 16 taps, is a kernel that gives each example to one wave and holds the image in registers). */
+ * 64x64 examples on the workgroup-per-example kernels (the default for that shape are kernels that
+ * give each example to one wave and hold the image in registers). */
 int wn_create(int device, wn_context** ctx);
 int wn_destroy(wn_context* ctx);
 /* A context starts on a stream of its own.  This switches it to the caller's hipStream_t (e.g. the

@@ -1,6 +1,6 @@
 """Parity of the HIP path against the CPU oracle, through the C ABI, on a real MI355X.
 
-Tolerance: the north star asks for <= 1e-9 relative per step on coefficients, activations,
+Tolerance: the requirement is <= 1e-9 relative per step on coefficients, activations,
 costs and filters; the kernels and the oracle differ only in summation order, so the bar used
 here is 1e-11 relative to the largest magnitude of each array (1e-9 for multi-step logs).
 """

@@ -74,7 +74,7 @@ def sparse_inputs(B, seed):
     return X
 
 
-@pytest.mark.parametrize("N", [2, 4, 6, 8, 12, 16])
+@pytest.mark.parametrize("N", [2, 4, 6, 8, 12, 16, 22, 32])
 @pytest.mark.parametrize("B", [1, 3, 4, 37])
 def test_against_oracle(ctx, oracle, N, B):
     a = filt_for(N, 1)
@@ -90,7 +90,7 @@ def test_against_oracle(ctx, oracle, N, B):
         assert S[e] == pytest.approx(se, rel=1e-12)
 
 
-@pytest.mark.parametrize("N", [2, 4, 8, 16])
+@pytest.mark.parametrize("N", [2, 4, 8, 16, 32])
 def test_many_passes_against_block_kernel(ctx, ctx_block, N):
     """More examples than one pass of the grid (1024 waves) holds; every example compared."""
     B = 2500

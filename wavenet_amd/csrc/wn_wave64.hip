@@ -8,6 +8,7 @@ extern "C" const void* wn_kernel_wave64(int np) {
         case 4: return (const void*)&wn::k_train64<4>;
         case 8: return (const void*)&wn::k_train64<8>;
         case 16: return (const void*)&wn::k_train64<16>;
+        case 32: return (const void*)&wn::k_train64<32>;
     }
     return nullptr;
 }
@@ -27,6 +28,7 @@ extern "C" const void* wn_kernel_wave64_transform(int kind, int np) {
         case 4: WN_W64_PAIR(4)
         case 8: WN_W64_PAIR(8)
         case 16: WN_W64_PAIR(16)
+        case 32: WN_W64_PAIR(32)
     }
     return nullptr;
 #undef WN_W64_PAIR
