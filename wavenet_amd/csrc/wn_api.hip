@@ -570,7 +570,8 @@ int wn_train_batch(wn_context* ctx, const double* X, int B, int R, int C, double
             rc = launch(ctx, wave64, 256, (size_t)4 * wn::W64_TILE * sizeof(double), (B + 3) / 4, A, &grid);
             grid *= 4;
         } else {
-            const size_t shmem = ((size_t)3 * R * C + S.NS + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double) + 16;
+            // X, row-stage coefficients (2D only), pyramid, coefficients / sort slots, reduction scratch
+            const size_t shmem = ((size_t)(lgC > 0 ? 3 : 2) * R * C + S.NS + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double) + 16;
             rc = launch(ctx, fused_kernel(ctx->NP, KIND_TRAIN, sc), S.T, shmem, B, A, &grid);
         }
         if (rc) return rc;

@@ -106,8 +106,11 @@ __global__ __launch_bounds__(T) void k_train(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
     const int lgR = A.lgR, lgC = A.lgC, R = 1 << lgR, n = 1 << (lgR + lgC);
+    // a 1D signal (one column) has no row stage: its row-stage coefficients are the signal itself,
+    // and the buffer for them is not allocated (the host sizes the LDS accordingly)
+    const bool twoD = lgC > 0;
     double* bufX = smem;
-    double* bufY1 = bufX + n;
+    double* bufY1 = twoD ? bufX + n : bufX;
     double* bufP = bufY1 + n;
     double* bufY = bufP + n;
     double* red = bufY + NS;
@@ -128,8 +131,8 @@ __global__ __launch_bounds__(T) void k_train(FusedArgs A) {
         __syncthreads();
         if (e + (int)gridDim.x < A.B) load_regs<T, K>(xpre, A.X + (size_t)(e + gridDim.x) * n, n, tid);
 
-        fwd_pass<NP, T>(bufX, bufP, bufY1, R, 1, lgR, lgC, true, a, b, tid);   // rows  (Wavenet.cxx:587-601)
-        fwd_pass<NP, T>(bufY1, bufP, bufY, 1, R, lgC, lgR, false, a, b, tid);  // cols  (Wavenet.cxx:604-619)
+        if (twoD) fwd_pass<NP, T>(bufX, bufP, bufY1, R, 1, lgR, lgC, true, a, b, tid);   // rows  (Wavenet.cxx:587-601)
+        fwd_pass<NP, T>(bufY1, bufP, bufY, 1, R, lgC, lgR, false, a, b, tid);  // cols  (Wavenet.cxx:604-619; :404-445 in 1D)
 
         const double S = gini_phase<T, Q, true>(bufY, n, red, flag, tid);      // CostFunctions.cxx:49-117
 
