@@ -1,9 +1,9 @@
 // Streamed path for examples that do not fit the LDS-resident kernels (R*C > 4096), e.g. 512x512
 // images and 2^20-sample signals.  Every level of the cascade is one kernel over a chunk of the
 // batch; pyramids, coefficients and errors live in a device workspace (288 GB of HBM make that
-// cheap), the Gini ranks come from two stable device-wide radix sorts per chunk (by magnitude, then
-// by example number, so equal magnitudes keep ascending index order), and all reductions are
-// two-stage and ordered (no atomics).
+// cheap), the Gini ranks come from stable device-wide radix sorts (one sort of 32-bit keys per slice of
+// the chunk plus an exact re-ranking of equal-key groups, see gini_large; two sorts on 64-bit keys as
+// the fallback), and all reductions are two-stage and ordered (no atomics).
 //
 // Reference stages: forward_ (src/Wavenet.cxx:404-445, 562-622), SparseTerm(Deriv)
 // (src/CostFunctions.cxx:6-117), backpropagate_ (src/Wavenet.cxx:474-556, 665-711).
