@@ -563,6 +563,7 @@ __global__ __launch_bounds__(256, 1) void k_inverse64(FusedArgs A) {
 
 
 // SparseTerm / SparseTermDeriv (src/CostFunctions.cxx:6-117) on sets of 4096 coefficients, one wave per set.
+template <int UNUSED = 0>   // a template only so that every translation unit may include this header
 __global__ __launch_bounds__(256, 1) void k_sparse64(FusedArgs A) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

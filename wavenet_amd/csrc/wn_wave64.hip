@@ -1,35 +1,26 @@
-// Instantiates the one-wave-per-example training kernel of 64x64 examples for the compiled tap
-// counts it supports and exports the kernel addresses.
+// Entry points to the one-wave-per-example kernels of 64x64 examples (wn_wave64.h): the kernels that
+// depend on the tap count are compiled per tap count in wn_wave64_np.hip.
 #include "wn_wave64.h"
 
-extern "C" const void* wn_kernel_wave64(int np) {
-    switch (np) {
-        case 2: return (const void*)&wn::k_train64<2>;
-        case 4: return (const void*)&wn::k_train64<4>;
-        case 8: return (const void*)&wn::k_train64<8>;
-        case 16: return (const void*)&wn::k_train64<16>;
-        case 32: return (const void*)&wn::k_train64<32>;
-    }
-    return nullptr;
-}
+extern "C" const void* wn_kernel_wave64_np2(int kind);
+extern "C" const void* wn_kernel_wave64_np4(int kind);
+extern "C" const void* wn_kernel_wave64_np8(int kind);
+extern "C" const void* wn_kernel_wave64_np16(int kind);
+extern "C" const void* wn_kernel_wave64_np32(int kind);
 
-extern "C" const void* wn_kernel_wave64_sparse() { return (const void*)&wn::k_sparse64; }
-
-// kind 1: forward transform, 2: inverse transform, 3: backpropagation (numbering of the
-// workgroup-per-example kernels)
+// kind 0: training step, 1: forward transform, 2: inverse transform, 3: backpropagation (the
+// numbering of the workgroup-per-example kernels)
 extern "C" const void* wn_kernel_wave64_transform(int kind, int np) {
-#define WN_W64_PAIR(NP)                                                  \
-    return kind == 1 ? (const void*)&wn::k_forward64<NP>                 \
-         : kind == 2 ? (const void*)&wn::k_inverse64<NP>                 \
-                     : (const void*)&wn::k_backprop64<NP>;
-    if (kind < 1 || kind > 3) return nullptr;
     switch (np) {
-        case 2: WN_W64_PAIR(2)
-        case 4: WN_W64_PAIR(4)
-        case 8: WN_W64_PAIR(8)
-        case 16: WN_W64_PAIR(16)
-        case 32: WN_W64_PAIR(32)
+        case 2: return wn_kernel_wave64_np2(kind);
+        case 4: return wn_kernel_wave64_np4(kind);
+        case 8: return wn_kernel_wave64_np8(kind);
+        case 16: return wn_kernel_wave64_np16(kind);
+        case 32: return wn_kernel_wave64_np32(kind);
     }
     return nullptr;
-#undef WN_W64_PAIR
 }
+
+extern "C" const void* wn_kernel_wave64(int np) { return wn_kernel_wave64_transform(0, np); }
+
+extern "C" const void* wn_kernel_wave64_sparse() { return (const void*)&wn::k_sparse64<0>; }
