@@ -244,3 +244,54 @@ def test_error_codes(ctx):
     ctx.set_filter(F.HAAR)
     ctx.train_batch(d, 0, 8, 8)  # empty batch: sums are zero
     assert np.all(ctx.sums() == 0)
+
+
+def test_contexts_release_their_device_memory():
+    """Creating, using (LDS-resident and streamed paths) and destroying contexts leaves no device memory
+    behind: the streamed path owns a workspace of hundreds of MB that wn_destroy must free."""
+    import torch
+    from wavenet_amd import Context
+    rng = np.random.default_rng(0)
+    Xs = to_dev(rng.random((3, 64, 64)))
+    Xl = to_dev(rng.random((2, 256, 128)))
+    torch.cuda.synchronize()
+    free0 = None
+    for it in range(6):
+        c = Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        c.set_filter(F.DB4)
+        c.train_batch(Xs, 3, 64, 64)
+        c.train_batch(Xl, 2, 256, 128)
+        c.sums()
+        c.close()
+        torch.cuda.synchronize()
+        free = torch.cuda.mem_get_info()[0]
+        if it == 1:
+            free0 = free   # after the first rounds: allocator pools and code objects are warm
+        if it > 1:
+            assert free0 - free < (16 << 20), (it, free0, free)
+
+
+def test_training_log_64x64_matches_dense_oracle(ctx, oracle):
+    """The benchmark's shape through the one-wave-per-example kernel: 6 updates of batch 4 against the
+    dense Wavenet restatement (filter log, cost log), tolerance 1e-9 per step."""
+    steps, Bsz, lam, alpha, N = 6, 4, 10.0, 1e-3, 4
+    a0 = filt_for(N, 4)
+    X = make_inputs(steps * Bsz, 64, 64, seed=21, sparse=True)
+    w = oracle.Wavenet(lam=lam, alpha=alpha)
+    w.set_batch_size(Bsz)
+    w.set_filter(a0)
+    for e in range(steps * Bsz):
+        assert w.train(X[e])
+    ofl = w.filter_log()[1:]
+    ocl = w.cost_log()[:-1]
+    ctx.set_filter(a0)
+    ctx.set_momentum(np.zeros(N))
+    ctx.clear_logs()
+    dX = to_dev(X)
+    for s in range(steps):
+        ctx.train_batch(dX[s * Bsz * 4096:].data_ptr(), Bsz, 64, 64)
+        ctx.apply_update(Bsz, Bsz * lam, alpha, 0.0, True)
+    fl, cl = ctx.logs()
+    step_err = np.abs(fl - ofl).max(axis=1) / np.abs(ofl).max(axis=1)
+    assert step_err.max() < 1e-9, step_err
+    assert np.abs(cl / ocl - 1).max() < 1e-9
