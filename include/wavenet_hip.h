@@ -177,6 +177,17 @@ int wn_num_updates(wn_context* ctx, int* steps);  /* synchronises */
 int wn_get_logs(wn_context* ctx, int first, int count, double* filters_host, double* costs_host);
 int wn_clear_logs(wn_context* ctx);
 
+/*
+ * Wavenet::costMap (src/Wavenet.cxx:278-324) evaluates cost(forward(X)) on a grid of filters, one
+ * setFilter + forward + SparseTerm per grid point and example.  This is the batched form of its
+ * device part: S_dev[f*B + e] = SparseTerm(forward(example e)) under filter f, for F filters of N
+ * taps each given row by row in filters_host.  The context's own filter, momentum and logs are not
+ * touched (none needs to be set); the regularisation term of each filter is wn_reg_term.  Examples
+ * of up to WN_MAX_FUSED samples; synchronises before returning.
+ */
+int wn_sparse_cost_grid(wn_context* ctx, const double* X_dev, int B, int R, int C,
+                        const double* filters_host, int F, int N, double* S_dev);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 /*
  * Brackets the training kernel of every following wn_train_batch with a pair of HIP events on

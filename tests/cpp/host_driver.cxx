@@ -82,6 +82,17 @@ int main(int argc, char** argv) {
             dump("inv1d", w.inverse_(coeffsFromActivations(a1)));
         }
         dump("basis", w.basisFunction(R, C, R > 1 ? 1 : 0, C > 1 ? 1 : 0));
+        {   // cost map over a 3 x 3 grid of 2-tap filters, two examples (X and D)
+            const Col keep = w.filter();
+            const size_t logged = w.filterLog().size();
+            std::vector<Mat> cm = w.costMap({X, D}, 1.5, 3);
+            dump("costmap", cm[0]);
+            dump("costmapSparse", cm[1]);
+            dump("costmapReg", cm[2]);
+            double grew = (double)(w.filterLog().size() - logged);
+            dump("costmapLogged", &grew, 1);
+            w.setFilter(keep);
+        }
         // error behaviour: odd filter and non radix-2 input are refused
         double flags[3] = {(double)w.setFilter(Col({1., 2., 3.})), (double)w.setFilter(Col()), (double)w.train(Mat(3, 1))};
         dump("refused", flags, 3);

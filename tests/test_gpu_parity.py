@@ -295,3 +295,32 @@ def test_training_log_64x64_matches_dense_oracle(ctx, oracle):
     step_err = np.abs(fl - ofl).max(axis=1) / np.abs(ofl).max(axis=1)
     assert step_err.max() < 1e-9, step_err
     assert np.abs(cl / ocl - 1).max() < 1e-9
+
+
+@pytest.mark.parametrize("R,C,N,F_", [(64, 64, 2, 30), (64, 64, 4, 5), (16, 8, 2, 9), (1024, 1, 6, 4), (64, 64, 32, 3)])
+def test_sparse_cost_grid(ctx, oracle, R, C, N, F_):
+    """wn_sparse_cost_grid (the device part of Wavenet::costMap, src/Wavenet.cxx:278-324) against one
+    set_filter + forward + sparse_term per filter, and against the oracle for the first filters.  The
+    context's own filter must come out untouched."""
+    import torch
+    B, n = 5, R * C
+    rng = np.random.default_rng(R + N + F_)
+    X = make_inputs(B, R, C, seed=F_, sparse=(n >= 256))
+    filters = rng.uniform(-1.2, 1.2, size=(F_, N))
+    mine = filt_for(4, 1)
+    ctx.set_filter(mine)
+    dX = to_dev(X)
+    dS = dev_empty(F_ * B)
+    ctx.sparse_cost_grid(dX, B, R, C, filters, dS)
+    S = dS.cpu().numpy().reshape(F_, B)
+    assert np.array_equal(ctx.filter(), mine)
+    dY, dS1 = dev_empty(B * n), dev_empty(B)
+    for f in range(F_):
+        ctx.set_filter(filters[f])
+        ctx.forward(dX, B, R, C, dY)
+        ctx.sparse_term(dY, B, n, dS1)
+        assert np.abs(S[f] - dS1.cpu().numpy()).max() < 1e-13, f
+    for f in range(min(F_, 3)):
+        for e in range(B):
+            Y = oracle.band_forward_2d(filters[f], X[e])[3]
+            assert S[f, e] == pytest.approx(oracle.sparse_term(Y), rel=1e-10)

@@ -61,6 +61,22 @@ def test_wavenet_methods(oracle, R, C, N):
     onehot = np.zeros((R, C))
     onehot[1 if R > 1 else 0, 1 if C > 1 else 0] = 1.0
     assert np.allclose(out["basis"], colmajor(w.inverse_2d(onehot)), **tol)
+    # costMap over a 3 x 3 grid of 2-tap filters (src/Wavenet.cxx:278-324): column-major (i, j) maps,
+    # a1 = grid[j], a2 = grid[i]; the all-zero filter in the middle has no Gini term (0/0)
+    grid = [-1.5, 0.0, 1.5]
+    sp, rg = np.zeros((3, 3)), np.zeros((3, 3))
+    for i in range(3):
+        for j in range(3):
+            f = np.array([grid[j], grid[i]])
+            w2 = oracle.Wavenet()
+            w2.set_filter(f)
+            with np.errstate(all="ignore"):
+                sp[i, j] = np.mean([oracle.sparse_term(w2.forward_2d(Z)[2]) for Z in (X, D)])
+            rg[i, j] = 10.0 * oracle.reg_term(f)
+    assert np.allclose(out["costmapSparse"], colmajor(sp), rtol=1e-10, atol=1e-12, equal_nan=True)
+    assert np.allclose(out["costmapReg"], colmajor(rg), rtol=1e-12, atol=0)
+    assert np.allclose(out["costmap"], colmajor(sp + rg), rtol=1e-10, atol=1e-12, equal_nan=True)
+    assert out["costmapLogged"][0] == 9.0    # one setFilter per grid point, as in the reference
     assert list(out["refused"]) == [0.0, 0.0, 0.0]
     assert "multiple of 2" in err and "empty" in err and "radix 2" in err
     if C == 1:

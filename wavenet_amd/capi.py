@@ -44,6 +44,7 @@ SIGNATURES = {
     "wn_sparse_term_deriv": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "wn_reg_term": (C.c_int, [_dp, C.c_int, C.c_int, _dp]),
     "wn_reg_term_deriv": (C.c_int, [_dp, C.c_int, C.c_int, _dp]),
+    "wn_sparse_cost_grid": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _vp]),
     "wn_train_batch": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "wn_sums": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_int)]),
     "wn_get_sums": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
@@ -225,6 +226,13 @@ class Context:
 
     def sparse_term_deriv(self, Y, B, n, Delta, S=None):
         self._check(self.lib.wn_sparse_term_deriv(self._h, _addr(Y), B, n, _addr(Delta), _addr(S)))
+
+    def sparse_cost_grid(self, X, B, R, Cc, filters, S):
+        """S[f * B + e] = sparse term of example e under filter f; filters: (F, N) numpy array."""
+        f = np.ascontiguousarray(filters, dtype=np.float64)
+        assert f.ndim == 2
+        self._check(self.lib.wn_sparse_cost_grid(self._h, _addr(X), B, R, Cc, f.ctypes.data_as(_dp), f.shape[0],
+                                                 f.shape[1], _addr(S)))
 
     # training -----------------------------------------------------------------------------------
     def train_batch(self, X, B, R, Cc, grad=None, S=None):

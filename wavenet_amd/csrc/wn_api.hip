@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <utility>
@@ -300,6 +301,8 @@ int wn_destroy(wn_context* ctx) {
     (void)hipFree(ctx->partial);
     (void)hipFree(ctx->own_sums);
     (void)hipFree(ctx->workspace);
+    if (ctx->grid_filters) (void)hipFree(ctx->grid_filters);
+    if (ctx->grid_scratch) (void)hipFree(ctx->grid_scratch);
     for (hipEvent_t ev : ctx->prof_begin) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->prof_end) (void)hipEventDestroy(ev);
     (void)hipFree(ctx->log_filters);
@@ -533,6 +536,89 @@ int wn_reg_term_deriv(const double* a, int N, int do_wavelet, double* grad) {
     if (N % 2) return WN_ERR_BAD_FILTER;
     if (N > 64) return WN_ERR_UNSUPPORTED;
     wn::reg_term_deriv(a, N, do_wavelet != 0, grad);
+    return WN_OK;
+}
+
+// ---- cost over a grid of filters ------------------------------------------------------------------------
+
+int wn_sparse_cost_grid(wn_context* ctx, const double* X, int B, int R, int C, const double* filters, int F, int N,
+                        double* S) {
+    int lgR, lgC, sc;
+    int rc = check_shape(ctx, B, R, C, false, &lgR, &lgC, &sc);
+    if (rc) return rc;
+    if (F < 0) return fail(ctx, WN_ERR_ARG, "negative filter count");
+    if (N <= 0) return fail(ctx, WN_ERR_BAD_FILTER, "Input filter is empty.");
+    if (N % 2) return fail(ctx, WN_ERR_BAD_FILTER, "Input filter length is not a multiple of 2.");
+    const int NP = compiled_taps(N);
+    if (NP < 0) return fail(ctx, WN_ERR_UNSUPPORTED, "filter length " + std::to_string(N) + " exceeds " + std::to_string(WN_MAX_TAPS));
+    if (sc < 0) return fail(ctx, WN_ERR_UNSUPPORTED, "cost grid: examples beyond " + std::to_string(WN_MAX_FUSED) + " samples are not supported");
+    if (B == 0 || F == 0) return WN_OK;
+    if (!X || !filters || !S) return fail(ctx, WN_ERR_ARG, "null pointer");
+    const int chunk = F < 4096 ? F : 4096;
+    if (ctx->grid_filters_cap < chunk) {
+        WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->grid_filters) (void)hipFree(ctx->grid_filters);
+        ctx->grid_filters = nullptr;
+        ctx->grid_filters_cap = 0;
+        WN_HIP(ctx, hipMalloc((void**)&ctx->grid_filters, (size_t)chunk * sizeof(wn::FilterDev)));
+        ctx->grid_filters_cap = chunk;
+    }
+    const void* w64 = (lgR == 6 && lgC == 6 && ctx->wave64) ? wn_kernel_wave64_transform(4, NP) : nullptr;
+    const size_t n = (size_t)R * C;
+    if (!w64 && ctx->grid_scratch_count < (size_t)B * n) {
+        WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->grid_scratch) (void)hipFree(ctx->grid_scratch);
+        ctx->grid_scratch = nullptr;
+        ctx->grid_scratch_count = 0;
+        WN_HIP(ctx, hipMalloc((void**)&ctx->grid_scratch, (size_t)B * n * sizeof(double)));
+        ctx->grid_scratch_count = (size_t)B * n;
+    }
+    std::vector<wn::FilterDev> table((size_t)chunk);
+    const int d = (NP - N) / 2;
+    for (int f0 = 0; f0 < F; f0 += chunk) {
+        const int Fc = (F - f0 < chunk) ? F - f0 : chunk;
+        memset(table.data(), 0, (size_t)Fc * sizeof(wn::FilterDev));
+        for (int f = 0; f < Fc; f++) {
+            const double* a = filters + (size_t)(f0 + f) * N;
+            wn::FilterDev& h = table[(size_t)f];
+            for (int j = 0; j < N; j++) {
+                h.a_true[j] = a[j];
+                h.a[j + d] = a[j];
+                h.b[j + d] = wn::parity_sign(j) * a[N - 1 - j];
+                h.vL[j + d] = 1.0;
+                h.sH[j + d] = wn::parity_sign(N - 1 - j);
+            }
+            h.N = N; h.NP = NP; h.d = d;
+        }
+        // the table is pageable host memory and is reused by the next chunk: wait for the kernels that read
+        // the previous one, copy synchronously
+        WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        WN_HIP(ctx, hipMemcpy(ctx->grid_filters, table.data(), (size_t)Fc * sizeof(wn::FilterDev), hipMemcpyHostToDevice));
+        wn::FusedArgs A;
+        memset(&A, 0, sizeof(A));
+        A.B = B; A.lgR = lgR; A.lgC = lgC; A.X = X;
+        if (w64) {
+            A.filt = ctx->grid_filters; A.F = Fc; A.S = S + (size_t)f0 * B;
+            const long long waves = (long long)Fc * B;
+            rc = launch(ctx, w64, 256, (size_t)4 * wn::W64_TILE * sizeof(double), (int)std::min<long long>((waves + 3) / 4, 1 << 30), A, nullptr);
+            if (rc) return rc;
+        } else {
+            const SizeClass& Sc = kSizeClasses[sc];
+            for (int f = 0; f < Fc; f++) {
+                wn::FusedArgs Af = A;
+                Af.filt = ctx->grid_filters + f; Af.Y = ctx->grid_scratch;
+                rc = launch(ctx, fused_kernel(NP, KIND_FORWARD, sc), Sc.T, (size_t)4 * n * sizeof(double), B, Af, nullptr);
+                if (rc) return rc;
+                wn::FusedArgs As;
+                memset(&As, 0, sizeof(As));
+                As.B = B; As.lgR = lgR + lgC; As.lgC = 0; As.Yin = ctx->grid_scratch; As.S = S + (size_t)(f0 + f) * B;
+                const size_t shmem = ((size_t)Sc.NS + Sc.T / 64 + 2) * sizeof(double) + 16;
+                rc = launch(ctx, wn_kernel_sparse(sc), Sc.T, shmem, B, As, nullptr);
+                if (rc) return rc;
+            }
+        }
+    }
+    WN_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `table` goes out of scope
     return WN_OK;
 }
 

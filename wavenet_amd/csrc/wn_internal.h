@@ -22,6 +22,10 @@ struct wn_context {
     int N = 0, NP = 0;
     double* partial = nullptr;
     int partial_blocks = 0;
+    wn::FilterDev* grid_filters = nullptr;   // table of filters for wn_sparse_cost_grid
+    int grid_filters_cap = 0;
+    double* grid_scratch = nullptr;           // coefficients of one batch (shapes without a fused cost kernel)
+    size_t grid_scratch_count = 0;
     bool exact_sort = false;  // streamed path: always the 64-bit sort (WAVENET_HIP_EXACT_SORT=1; for tests)
     bool wave64 = true;  // 64x64 training on the one-wave-per-example kernel (WAVENET_HIP_WAVE64=0 turns it off)
     double* sums = nullptr;

@@ -30,6 +30,7 @@ struct FusedArgs {
     double* S;        // [B] sparse term per example
     double* grad;     // [B][N] sparsity gradient per example
     double* partial;  // [grid][PSTRIDE] per-workgroup sums: N gradient entries, S, non-finite count
+    int F;            // cost grid only: number of filters in the table `filt` points to
 };
 
 template <int T, int K>

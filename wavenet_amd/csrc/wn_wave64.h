@@ -642,6 +642,38 @@ __global__ __launch_bounds__(256, 1) void k_backprop64(FusedArgs A) {
     }
 }
 
+
+// Sparsity cost of every 64x64 example under every filter of a table (Wavenet::costMap,
+// src/Wavenet.cxx:278-324, evaluates cost(forward(X)) over a grid of filters): work item w = f * B + e
+// is one wave's forward transform and Gini term, S[w] the result.  The taps change per item, so they
+// are fetched inside the loop.
+template <int NP>
+__global__ __launch_bounds__(256, 1) void k_cost64(FusedArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nslots = gridDim.x * 4;
+    const long long items = (long long)A.F * A.B;
+    for (long long item = blockIdx.x * 4 + wave; item < items; item += nslots) {
+        const int f = (int)(item / A.B), e = (int)(item - (long long)f * A.B);
+        const FilterDev* filt = A.filt + f;
+        double a[NP], b[NP];
+#pragma unroll
+        for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+        unsigned tile_off = (unsigned)wave * W64_TILE;
+        asm volatile("" : "+s"(tile_off));
+        double* tile = smem + tile_off;
+        double* trow = tile + lane * 65;
+        double v[64], w[64], p[64];
+        w64_load_rows(v, A.X + (size_t)e * 4096, lane);
+        w64_fwd_levels<NP, 5, true>(v, p, w, trow, a, b);
+        w64_read_transposed(w, tile, lane);
+        w64_fwd_levels<NP, 5, false>(w, p, v, trow, a, b);   // v = Y(:, lane)
+        const W64Rank rank = w64_rank_sort(v, tile, lane);
+        const double S = w64_gini_finish(v, rank, tile, lane);
+        if (lane == 0) A.S[item] = S;
+    }
+}
+
 // ---- kernel ---------------------------------------------------------------------------------------------
 // 256 threads = 4 waves = 4 examples in flight per workgroup; grid-stride over the batch.
 template <int NP>

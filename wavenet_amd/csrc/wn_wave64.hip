@@ -9,7 +9,7 @@ extern "C" const void* wn_kernel_wave64_np16(int kind);
 extern "C" const void* wn_kernel_wave64_np32(int kind);
 
 // kind 0: training step, 1: forward transform, 2: inverse transform, 3: backpropagation (the
-// numbering of the workgroup-per-example kernels)
+// numbering of the workgroup-per-example kernels), 4: sparsity cost over a table of filters
 extern "C" const void* wn_kernel_wave64_transform(int kind, int np) {
     switch (np) {
         case 2: return wn_kernel_wave64_np2(kind);

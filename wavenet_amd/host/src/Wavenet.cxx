@@ -277,21 +277,47 @@ std::vector<Mat> Wavenet::costMap(const std::vector<Mat>& X, const double& range
     double* dY = dev.buf(DeviceSession::Y, host.size());
     double* dS = dev.buf(DeviceSession::S, nExample);
     if (!dev.up(dX, host.data(), host.size())) return costs;
+    // all grid points in one call where the library has a batched kernel for the shape ...
+    const std::size_t F = (std::size_t)Ndiv * Ndiv;
+    std::vector<double> grid(2 * F), Sall(F * nExample);
     for (unsigned i = 0; i < Ndiv; i++) {
         for (unsigned j = 0; j < Ndiv; j++) {
-            const double a1 = (2 * j / double(Ndiv - 1) - 1) * range;
-            const double a2 = (2 * i / double(Ndiv - 1) - 1) * range;
-            setFilter({a1, a2});
-            bool ok = dev.ok(wn_forward(dev.ctx, dX, (int)nExample, (int)R, (int)C, dY, nullptr, nullptr, nullptr)) &&
-                      dev.ok(wn_sparse_term(dev.ctx, dY, (int)nExample, (int)n, dS)) && dev.down(S.data(), dS, nExample);
-            if (!ok) return costs;
-            const double reg = lambda() * RegTerm(m_filter, m_wavelet);
+            grid[2 * ((std::size_t)i * Ndiv + j)] = (2 * j / double(Ndiv - 1) - 1) * range;
+            grid[2 * ((std::size_t)i * Ndiv + j) + 1] = (2 * i / double(Ndiv - 1) - 1) * range;
+        }
+    }
+    double* dSall = dev.buf(DeviceSession::DELTA, Sall.size());
+    const int st = dSall ? wn_sparse_cost_grid(dev.ctx, dX, (int)nExample, (int)R, (int)C, grid.data(), (int)F, 2, dSall) : WN_ERR_HIP;
+    const bool batched = (st == WN_OK) && dev.down(Sall.data(), dSall, Sall.size());
+    if (!batched && st != WN_ERR_UNSUPPORTED) { dev.ok(st); return costs; }
+    for (unsigned i = 0; i < Ndiv; i++) {
+        for (unsigned j = 0; j < Ndiv; j++) {
+            const std::size_t f = (std::size_t)i * Ndiv + j;
+            const Col point({grid[2 * f], grid[2 * f + 1]});
+            if (batched) {
+                for (unsigned e = 0; e < nExample; e++) S[e] = Sall[f * nExample + e];
+                // setFilter's host-side effects at every grid point (src/Wavenet.cxx:297-299): the filter
+                // log grows by one entry; the device gets the last point's filter after the loop
+                m_filter = point;
+                m_filterLog.push_back(m_filter);
+            } else {
+                // ... else point by point (examples beyond the fused kernels' size)
+                setFilter(point);
+                bool ok = dev.ok(wn_forward(dev.ctx, dX, (int)nExample, (int)R, (int)C, dY, nullptr, nullptr, nullptr)) &&
+                          dev.ok(wn_sparse_term(dev.ctx, dY, (int)nExample, (int)n, dS)) && dev.down(S.data(), dS, nExample);
+                if (!ok) return costs;
+            }
+            const double reg = lambda() * RegTerm(point, m_wavelet);
             for (unsigned e = 0; e < nExample; e++) {
                 costs[0](i, j) += S[e] + reg;
                 costs[1](i, j) += S[e];
                 costs[2](i, j) += reg;
             }
         }
+    }
+    if (batched && F > 0) {
+        if (m_momentum.n_elem != m_filter.n_elem) m_momentum.zeros(m_filter.n_elem);
+        if (!dev.ok(wn_set_filter(dev.ctx, m_filter.memptr(), (int)m_filter.n_elem))) return costs;
     }
     for (Mat& M : costs) {
         for (std::size_t k = 0; k < M.n_elem; k++) M(k) /= (double)nExample;
