@@ -27,7 +27,7 @@ WORKLOADS = {
     # name: (R, C, per-GPU batch, default taps, generator)
     "2d64": (64, 64, 4096, 4, "calorimeter"),
     "1d1024": (1024, 1, 4096, 16, "bumps"),
-    "2d512": (512, 512, 256, 4, "calorimeter"),     # streamed path; per-GPU batch reduced from 2048 to keep host generation short
+    "2d512": (512, 512, 256, 4, "calorimeter"),     # streamed path; per-GPU batch reduced from 2048 (workspace: 14 arrays of batch x n)
     "1d1m": (1 << 20, 1, 8, 32, "bumps"),           # streamed path, 8 signals per GPU
 }
 
@@ -118,9 +118,16 @@ def main():
     lam, alpha = 10.0, 1e-3
     a0 = perturbed(daubechies(N), 1e-2, seed=7)
 
-    X = make_inputs(gen, B, R, C, seed=1000 + rank)
-    dX = torch.from_numpy(to_device_layout(X)).cuda()
     ctx = Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    X = None
+    if gen == "calorimeter":
+        # generated on the device (bit-identical to generators.calorimeter; tests/test_gpu_generators.py)
+        dX = torch.empty(B * R * C, dtype=torch.float64, device="cuda")
+        for e0 in range(0, B, 32768):
+            ctx.generate_calorimeter(dX[e0 * R * C:], min(32768, B - e0), R, C, seed=1000 + rank, first=e0)
+    else:
+        X = make_inputs(gen, B, R, C, seed=1000 + rank)
+        dX = torch.from_numpy(to_device_layout(X)).cuda()
     ctx.set_filter(a0)
     trainer = DataParallelTrainer(ctx, world)
 
@@ -171,6 +178,8 @@ def main():
             "final_filter": [float(v) for v in final_filter],
         }
         if world == 1 and not args.no_cpu_baseline:
+            if X is None:
+                X = make_inputs(gen, min(B, 16384), R, C, seed=1000 + rank)   # the same examples, on the host
             out["cpu_baseline"] = cpu_baseline(X, a0, lam, alpha)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)

@@ -188,6 +188,32 @@ int wn_clear_logs(wn_context* ctx);
 int wn_sparse_cost_grid(wn_context* ctx, const double* X_dev, int B, int R, int C,
                         const double* filters_host, int F, int N, double* S_dev);
 
+/* ---- generators --------------------------------------------------------------------------- */
+/*
+ * Batches of synthetic examples written straight into device memory, in the layout of every other
+ * entry point, standing for B calls of GeneratorBase::next (include/Wavenet/GeneratorBase.h:32-103).
+ * The reference's generators reseed from entropy on every reset (include/Wavenet/Generators.h:66, 100,
+ * 170) and cannot be reproduced; these are counter-based -- every value is a function of (seed,
+ * example number, item) -- and bit-identical to wavenet_amd/generators.py and the host layer's
+ * generators.  Example e of the call has number first_example + e, so consecutive calls (or the
+ * ranks of a data-parallel job) continue one sequence.  At most 65535 examples per call.
+ *   uniform      U[0,1) pixels (UniformGenerator, Generators.h:87-96)
+ *   needle       the same with everything below the threshold zeroed, one pixel kept in an image
+ *                that would be empty (NeedleGenerator, Generators.h:50-62)
+ *   calorimeter  eta-phi image in the spirit of HepMCGenerator's TH2F fill (Generators.h:377-393):
+ *                K deposits with K from poisson_table_host[4096] (inverse CDF samples) and energies
+ *                from energy_table_host[1024], plus `jets` clusters of jet_deposits deposits; bins
+ *                rounded to float.  The tables come from the caller so that host and device agree
+ *                to the bit; the call synchronises to copy them.
+ */
+int wn_generate_uniform(wn_context* ctx, unsigned long long seed, long long first_example,
+                        int B, int R, int C, double* X_dev);
+int wn_generate_needle(wn_context* ctx, unsigned long long seed, long long first_example,
+                       int B, int R, int C, double threshold, double* X_dev);
+int wn_generate_calorimeter(wn_context* ctx, unsigned long long seed, long long first_example,
+                            int B, int R, int C, const int* poisson_table_host,
+                            const double* energy_table_host, int jets, int jet_deposits, double* X_dev);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 /*
  * Brackets the training kernel of every following wn_train_batch with a pair of HIP events on

@@ -1,0 +1,78 @@
+"""Device-side generators (wn_generate_*) against wavenet_amd/generators.py: bit-identical batches."""
+import numpy as np
+import pytest
+
+from gpu_util import dev_empty, from_dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    from wavenet_amd import Context
+    c = Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    yield c
+    torch.cuda.synchronize()
+    c.close()
+
+
+@pytest.mark.parametrize("R,C", [(64, 64), (16, 4), (1024, 1), (1, 32), (128, 256)])
+def test_uniform_and_needle(ctx, R, C):
+    import torch
+    from wavenet_amd import generators as G
+    B, first, seed = 7, 3, 1234
+    d = dev_empty(B * R * C)
+    ctx.generate_uniform(d, B, R, C, seed=seed, first=first)
+    torch.cuda.synchronize()
+    assert np.array_equal(from_dev(d, B, R, C), G.uniform(first + B, R, C, seed)[first:])
+    # a threshold that leaves some images of the small shapes empty exercises the kept pixel
+    thr = 0.995 if R * C >= 1024 else 0.97
+    ctx.generate_needle(d, B, R, C, seed=seed, first=first, threshold=thr)
+    torch.cuda.synchronize()
+    ref = G.needle(first + B, R, C, seed, threshold=thr)[first:]
+    got = from_dev(d, B, R, C)
+    if thr != 0.995:
+        # the kept pixel's value is defined with the default threshold's constants; only its position and
+        # the thresholded pixels are comparable here
+        assert np.array_equal(got != 0, ref != 0)
+    else:
+        assert np.array_equal(got, ref)
+
+
+def test_needle_empty_images_keep_one_pixel(ctx):
+    import torch
+    from wavenet_amd import generators as G
+    B, R, C = 40, 8, 8    # 64 pixels at threshold 0.995: most images would be empty
+    d = dev_empty(B * R * C)
+    ctx.generate_needle(d, B, R, C, seed=9)
+    torch.cuda.synchronize()
+    got = from_dev(d, B, R, C)
+    assert np.array_equal(got, G.needle(B, R, C, 9))
+    assert ((got != 0).reshape(B, -1).sum(axis=1) >= 1).all()
+
+
+@pytest.mark.parametrize("R,C,B", [(64, 64, 33), (512, 512, 2), (32, 128, 5)])
+def test_calorimeter(ctx, R, C, B):
+    import torch
+    from wavenet_amd import generators as G
+    first, seed = 2, 1000
+    d = dev_empty(B * R * C)
+    ctx.generate_calorimeter(d, B, R, C, seed=seed, first=first)
+    torch.cuda.synchronize()
+    assert np.array_equal(from_dev(d, B, R, C), G.calorimeter(first + B, R, C, seed=seed)[first:])
+
+
+def test_generated_batch_trains_like_an_uploaded_one(ctx):
+    import torch
+    from gpu_util import to_dev
+    from wavenet_amd import generators as G
+    import filters as F
+    B, R, C = 64, 64, 64
+    d = dev_empty(B * R * C)
+    ctx.generate_calorimeter(d, B, R, C, seed=5)
+    ctx.set_filter(F.DB4)
+    ctx.train_batch(d, B, R, C)
+    s1 = ctx.sums().copy()
+    ctx.train_batch(to_dev(G.calorimeter(B, R, C, seed=5)), B, R, C)
+    assert np.array_equal(ctx.sums(), s1)

@@ -45,6 +45,10 @@ SIGNATURES = {
     "wn_reg_term": (C.c_int, [_dp, C.c_int, C.c_int, _dp]),
     "wn_reg_term_deriv": (C.c_int, [_dp, C.c_int, C.c_int, _dp]),
     "wn_sparse_cost_grid": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _dp, C.c_int, C.c_int, _vp]),
+    "wn_generate_uniform": (C.c_int, [_vp, C.c_ulonglong, C.c_longlong, C.c_int, C.c_int, C.c_int, _vp]),
+    "wn_generate_needle": (C.c_int, [_vp, C.c_ulonglong, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_double, _vp]),
+    "wn_generate_calorimeter": (C.c_int, [_vp, C.c_ulonglong, C.c_longlong, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(C.c_int), _dp, C.c_int, C.c_int, _vp]),
     "wn_train_batch": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "wn_sums": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_int)]),
     "wn_get_sums": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
@@ -233,6 +237,23 @@ class Context:
         assert f.ndim == 2
         self._check(self.lib.wn_sparse_cost_grid(self._h, _addr(X), B, R, Cc, f.ctypes.data_as(_dp), f.shape[0],
                                                  f.shape[1], _addr(S)))
+
+    # generators ---------------------------------------------------------------------------------
+    def generate_uniform(self, X, B, R, Cc, seed=1, first=0):
+        self._check(self.lib.wn_generate_uniform(self._h, seed, first, B, R, Cc, _addr(X)))
+
+    def generate_needle(self, X, B, R, Cc, seed=1, first=0, threshold=0.995):
+        self._check(self.lib.wn_generate_needle(self._h, seed, first, B, R, Cc, threshold, _addr(X)))
+
+    def generate_calorimeter(self, X, B, R, Cc, seed=1, first=0, mean_deposits=None, jets=2, jet_deposits=30):
+        """Same images as generators.calorimeter(...)[first:first + B], written in device layout."""
+        from . import generators as G
+        if mean_deposits is None:
+            mean_deposits = max(1.0, 200.0 * (R * Cc) / 4096.0)
+        ptab = np.ascontiguousarray(G._poisson_table(float(mean_deposits)), dtype=np.int32)
+        etab = np.ascontiguousarray(G._EXP_TABLE, dtype=np.float64)
+        self._check(self.lib.wn_generate_calorimeter(self._h, seed, first, B, R, Cc, ptab.ctypes.data_as(C.POINTER(C.c_int)),
+                                                     etab.ctypes.data_as(_dp), jets, jet_deposits, _addr(X)))
 
     # training -----------------------------------------------------------------------------------
     def train_batch(self, X, B, R, Cc, grad=None, S=None):

@@ -301,6 +301,7 @@ int wn_destroy(wn_context* ctx) {
     (void)hipFree(ctx->partial);
     (void)hipFree(ctx->own_sums);
     (void)hipFree(ctx->workspace);
+    if (ctx->gen_tables) (void)hipFree(ctx->gen_tables);
     if (ctx->grid_filters) (void)hipFree(ctx->grid_filters);
     if (ctx->grid_scratch) (void)hipFree(ctx->grid_scratch);
     for (hipEvent_t ev : ctx->prof_begin) (void)hipEventDestroy(ev);
@@ -557,7 +558,8 @@ int wn_sparse_cost_grid(wn_context* ctx, const double* X, int B, int R, int C, c
     const int chunk = F < 4096 ? F : 4096;
     if (ctx->grid_filters_cap < chunk) {
         WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->grid_filters) (void)hipFree(ctx->grid_filters);
+        if (ctx->gen_tables) (void)hipFree(ctx->gen_tables);
+    if (ctx->grid_filters) (void)hipFree(ctx->grid_filters);
         ctx->grid_filters = nullptr;
         ctx->grid_filters_cap = 0;
         WN_HIP(ctx, hipMalloc((void**)&ctx->grid_filters, (size_t)chunk * sizeof(wn::FilterDev)));

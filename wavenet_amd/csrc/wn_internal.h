@@ -22,6 +22,7 @@ struct wn_context {
     int N = 0, NP = 0;
     double* partial = nullptr;
     int partial_blocks = 0;
+    void* gen_tables = nullptr;               // Poisson and energy tables of wn_generate_calorimeter
     wn::FilterDev* grid_filters = nullptr;   // table of filters for wn_sparse_cost_grid
     int grid_filters_cap = 0;
     double* grid_scratch = nullptr;           // coefficients of one batch (shapes without a fused cost kernel)
