@@ -179,7 +179,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             if X is None:
-                X = make_inputs(gen, min(B, 16384), R, C, seed=1000 + rank)   # the same examples, on the host
+                X = make_inputs(gen, min(2 * B, 16384), R, C, seed=1000 + rank)   # the same sequence of examples, on the host
             out["cpu_baseline"] = cpu_baseline(X, a0, lam, alpha)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
