@@ -145,6 +145,7 @@ int main(int argc, char** argv) {
         coach.setUseAdaptiveBatchSize((flags >> 1) & 1u);
         coach.setUseSimulatedAnnealing((flags >> 2) & 1u);
         if (target > 0) coach.setTargetPrecision(target);
+        if (std::getenv("WAVENET_TEST_HOST_GENERATE")) coach.setGenerateOnDevice(false);
         if (!coach.run()) return 4;
         dumpLogs(w);
         return 0;

@@ -16,13 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DRIVER = os.path.join(ROOT, "tests", "cpp", "host_driver")
 
 
-def run_driver(args, arrays):
+def run_driver(args, arrays, env=None):
     assert os.path.exists(DRIVER), "build it with make -C tests/cpp (done by __graft_entry__.build())"
     with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
         np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in arrays]).tofile(f)
         path = f.name
     try:
-        res = subprocess.run([DRIVER] + [str(a) for a in args] + [path], capture_output=True, text=True, timeout=300)
+        res = subprocess.run([DRIVER] + [str(a) for a in args] + [path], capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, **env) if env else None)
     finally:
         os.unlink(path)
     assert res.returncode == 0, (res.returncode, res.stdout[-500:], res.stderr[-2000:])
@@ -129,3 +130,16 @@ def test_coach_run_matches_oracle(oracle, flags, events, epochs, batch, target):
     assert np.allclose(out["costLog"], ocl, rtol=1e-9, atol=1e-15)
     lam, alpha, bs = out["misc"]
     assert lam == pytest.approx(w.lam(), rel=1e-14) and alpha == w.alpha() and bs == w.batch_size()
+
+
+def test_coach_generates_on_the_device_or_on_the_host_alike():
+    """Coach fills its batches on the device when the generator has a device form (the default, which
+    the test above pins against the oracle); gathering the same examples from next() on the host must
+    give the very same logs."""
+    R, C, N, seed = 16, 16, 4, 7
+    a = F.perturbed(F.DB4, 5e-2, 5)
+    args = ["coach", R, C, N, 96, 2, 8, 4, seed, -1]
+    dev, _ = run_driver(args, [a])
+    host, _ = run_driver(args, [a], env={"WAVENET_TEST_HOST_GENERATE": "1"})
+    assert np.array_equal(dev["filterLog"], host["filterLog"])
+    assert np.array_equal(dev["costLog"], host["costLog"])

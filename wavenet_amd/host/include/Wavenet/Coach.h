@@ -38,6 +38,9 @@ public:
     // every initialisation) or PointOnNSphere(numCoeffs, 0, seed + init).
     void setInitialFilter(const Col& filter) { m_initialFilter = filter; }
     void setSeed(std::uint64_t seed) { m_seed = seed; }
+    // examples are generated on the device when the generator can do that (default); off: always next()
+    void setGenerateOnDevice(bool flag = true) { m_generateOnDevice = flag; }
+    bool generateOnDevice() const { return m_generateOnDevice; }
 
     /// Get method(s).
     std::string name() const { return m_name; }
@@ -74,6 +77,7 @@ private:
     unsigned m_printLevel = 0;
     Col m_initialFilter;
     std::uint64_t m_seed = 1;
+    bool m_generateOnDevice = true;
 };
 
 }  // namespace wavenet

@@ -9,6 +9,8 @@
 #include "Wavenet/Logger.h"
 #include "Wavenet/Matrix.h"
 
+struct wn_context;
+
 namespace wavenet {
 
 class GeneratorBase {
@@ -20,6 +22,13 @@ public:
     virtual bool open() { return true; }
     virtual bool close() { return true; }
     bool reset() { return close() && open(); }
+
+    // Optional fast path with no counterpart in the reference: the next `count` examples written
+    // straight into device memory (column-major, contiguous: the layout of wavenet_hip.h), advancing
+    // the sequence exactly as `count` calls of next() would.  Returns false (and generates nothing)
+    // when the generator has no device form; Coach then gathers from next() as usual.
+    virtual bool nextOnDevice(wn_context* /*ctx*/, double* /*X_dev*/, unsigned /*count*/) { return false; }
+    virtual bool hasDeviceForm() const { return false; }
 
     bool setShape(const std::vector<unsigned>& shape);
     std::vector<unsigned> shape() const { return m_shape; }

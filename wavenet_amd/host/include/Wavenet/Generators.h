@@ -27,12 +27,16 @@ protected:
 class UniformGenerator : public SeededGenerator {
 public:
     const Mat& next() override;
+    bool nextOnDevice(wn_context* ctx, double* X_dev, unsigned count) override;
+    bool hasDeviceForm() const override { return true; }
 };
 
 // U[0,1) pixels with everything below 0.995 set to zero; never an all-zero example.
 class NeedleGenerator : public SeededGenerator {
 public:
     const Mat& next() override;
+    bool nextOnDevice(wn_context* ctx, double* X_dev, unsigned count) override;
+    bool hasDeviceForm() const override { return true; }
 };
 
 // One to three unit-height Gaussian bumps at random positions and widths.

@@ -21,6 +21,7 @@ struct wn_context;
 
 namespace wavenet {
 
+class GeneratorBase;
 class DeviceSession;  // device buffers and the wn_context of one Wavenet object
 
 class Wavenet {
@@ -70,6 +71,9 @@ public:
     // the batch queue.  lambdas (optional, B values) is the regularisation constant per example
     // for Coach's annealing; otherwise lambda() is used.
     bool trainBatch(const double* X, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas = nullptr);
+    // The same with the B examples drawn from a generator that can write them on the device
+    // (GeneratorBase::nextOnDevice); false without touching anything if it cannot.
+    bool trainBatchFrom(GeneratorBase& generator, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas = nullptr);
     void clear();
 
     /// High-level cost method(s).
@@ -115,6 +119,7 @@ private:
     bool checkShape_(unsigned nRows, unsigned nCols) const;
     // forward + sparsity gradient + backpropagation of `count` examples already on the device,
     // per-example results into the batch queue and the cost log (the slow, exact path of train()).
+    bool trainOnDevice_(const double* dX, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas);
     bool queueExamples_(const double* X_dev, unsigned count, unsigned nRows, unsigned nCols, const double* lambdas);
 
     double m_lambda = 10.0;

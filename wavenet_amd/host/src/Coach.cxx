@@ -89,10 +89,27 @@ bool Coach::run() {
                 const unsigned bs = (unsigned)std::max(1, m_wavenet->batchSize());
                 unsigned chunk = adaptive ? bs : bs * std::max(1u, 4096u / bs);
                 if (m_numEvents >= 0) chunk = std::min<unsigned>(chunk, (unsigned)(m_numEvents - event));
-                staging.resize((std::size_t)chunk * n);
                 lambdas.resize(chunk);
+                // a generator with a device form writes the chunk where the kernels read it
+                const bool onDevice = m_generateOnDevice && m_generator->hasDeviceForm() && chunk <= 65535u;
+                if (!onDevice) staging.resize((std::size_t)chunk * n);
                 unsigned got = 0;
-                for (; got < chunk; got++) {
+                if (onDevice) {
+                    for (; got < chunk; got++) {
+                        if (useSimulatedAnnealing()) {                                  // :176-180
+                            const double f = (event + (int)got + (int)epoch * numEvents()) / float(numEvents() * (int)numEpochs());
+                            lambdas[got] = lambdaBare * f / sq(2 - f);
+                        } else {
+                            lambdas[got] = m_wavenet->lambda();
+                        }
+                    }
+                    const bool status = m_wavenet->trainBatchFrom(*m_generator, got, nRows, nCols,
+                                                                  useSimulatedAnnealing() ? lambdas.data() : nullptr);
+                    if (!m_generator->good()) generatorGood = false;                    // :264
+                    event += (int)got;
+                    if (!status) { done = true; break; }                                // :186-189
+                }
+                for (; !onDevice && got < chunk; got++) {
                     if (useSimulatedAnnealing()) {                                      // :176-180
                         const double f = (event + (int)got + (int)epoch * numEvents()) / float(numEvents() * (int)numEpochs());
                         lambdas[got] = lambdaBare * f / sq(2 - f);
@@ -103,10 +120,12 @@ bool Coach::run() {
                     std::memcpy(staging.data() + (std::size_t)got * n, X.memptr(), n * sizeof(double));
                     if (!m_generator->good()) { generatorGood = false; got++; break; }  // :264
                 }
-                const bool status = m_wavenet->trainBatch(staging.data(), got, nRows, nCols,
-                                                          useSimulatedAnnealing() ? lambdas.data() : nullptr);
-                event += (int)got;
-                if (!status) { done = true; break; }                                    // :186-189
+                if (!onDevice) {
+                    const bool status = m_wavenet->trainBatch(staging.data(), got, nRows, nCols,
+                                                              useSimulatedAnnealing() ? lambdas.data() : nullptr);
+                    event += (int)got;
+                    if (!status) { done = true; break; }                                // :186-189
+                }
 
                 if (adaptive) {                                                         // :192-250
                     previousCostLogSize = currentCostLogSize;

@@ -2,6 +2,7 @@
 
 #include "Wavenet/GeneratorBase.h"
 #include "Wavenet/Generators.h"
+#include "wavenet_hip.h"
 #include "Wavenet/Utilities.h"
 
 namespace wavenet {
@@ -57,6 +58,22 @@ const Mat& NeedleGenerator::next() {
         m_data(pos / C, pos % C) = 0.995 + 0.005 * unitFromHash(hashCounters(m_seed ^ 0xBEEFull, {e}));
     }
     return m_data;
+}
+
+// The same sequences, a batch at a time, written by the device (wn_generate_* of wavenet_hip.h).
+bool UniformGenerator::nextOnDevice(wn_context* ctx, double* X_dev, unsigned count) {
+    if (!check_() || !ctx || count > 65535u) return false;
+    if (wn_generate_uniform(ctx, m_seed, (long long)m_event, (int)count, (int)m_shape[0], (int)m_shape[1], X_dev) != WN_OK) return false;
+    m_event += count;
+    return true;
+}
+
+bool NeedleGenerator::nextOnDevice(wn_context* ctx, double* X_dev, unsigned count) {
+    if (!check_() || !ctx || count > 65535u) return false;
+    if (wn_generate_needle(ctx, m_seed, (long long)m_event, (int)count, (int)m_shape[0], (int)m_shape[1], 0.995, X_dev) != WN_OK)
+        return false;
+    m_event += count;
+    return true;
 }
 
 const Mat& GaussianGenerator::next() {

@@ -1,4 +1,5 @@
 #include "Wavenet/Wavenet.h"
+#include "Wavenet/GeneratorBase.h"
 
 #include <algorithm>
 #include <cassert>
@@ -194,10 +195,26 @@ bool Wavenet::trainBatch(const double* X, unsigned B, unsigned nRows, unsigned n
     DeviceSession& dev = device_();
     if (!dev.ctx) return false;
     const std::size_t n = (std::size_t)nRows * nCols;
-    const int N = (int)m_filter.n_elem;
     double* dX = dev.buf(DeviceSession::X, (std::size_t)B * n);
     if (!dev.up(dX, X, (std::size_t)B * n)) return false;
+    return trainOnDevice_(dX, B, nRows, nCols, lambdas);
+}
 
+bool Wavenet::trainBatchFrom(GeneratorBase& generator, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas) {
+    if (!generator.hasDeviceForm() || !checkShape_(nRows, nCols)) return false;
+    if (B == 0) return true;
+    DeviceSession& dev = device_();
+    if (!dev.ctx) return false;
+    double* dX = dev.buf(DeviceSession::X, (std::size_t)B * nRows * nCols);
+    if (!dX || !generator.nextOnDevice(dev.ctx, dX, B)) return false;
+    return trainOnDevice_(dX, B, nRows, nCols, lambdas);
+}
+
+// B examples already on the device: whole batches back to back, the rest through the batch queue.
+bool Wavenet::trainOnDevice_(const double* dX, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas) {
+    DeviceSession& dev = device_();
+    const std::size_t n = (std::size_t)nRows * nCols;
+    const int N = (int)m_filter.n_elem;
     unsigned done = 0;
     while (done < B) {
         const unsigned room = m_batchSize > m_batchQueue.size() ? m_batchSize - (unsigned)m_batchQueue.size() : 1;
