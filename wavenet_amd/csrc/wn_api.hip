@@ -29,6 +29,7 @@ extern "C" const void* wn_kernel_np32(int kind, int sc);
 extern "C" const void* wn_kernel_wave64(int np);
 extern "C" const void* wn_kernel_wave64_transform(int kind, int np);
 extern "C" const void* wn_kernel_wave64_sparse();
+extern "C" const void* wn_kernel_wave1d(int np);
 extern "C" const void* wn_kernel_sparse(int sc);
 
 namespace {
@@ -275,7 +276,7 @@ int wn_create(int device, wn_context** out) {
     };
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) rc = WN_ERR_HIP;
     ctx->own_stream = true;
-    ctx->partial_blocks = ctx->numCU * 16;
+    ctx->partial_blocks = ctx->numCU * 32;
     if (const char* w = getenv("WAVENET_HIP_WAVE64")) ctx->wave64 = (w[0] != '0');
     if (const char* w = getenv("WAVENET_HIP_EXACT_SORT")) ctx->exact_sort = (w[0] == '1');
     if (rc == WN_OK) alloc((void**)&ctx->dfilt, sizeof(wn::FilterDev));
@@ -657,6 +658,9 @@ int wn_train_batch(wn_context* ctx, const double* X, int B, int R, int C, double
             // one wave per example, four examples per workgroup; one partial-sum slot per wave
             rc = launch(ctx, wave64, 256, (size_t)4 * wn::W64_TILE * sizeof(double), (B + 3) / 4, A, &grid);
             grid *= 4;
+        } else if (lgR == 10 && lgC == 0 && ctx->wave64) {
+            // 1D signals of 1024 samples: one wave per example, one example in flight per workgroup
+            rc = launch(ctx, wn_kernel_wave1d(ctx->NP), 64, (size_t)(1024 + 8) * sizeof(double), B, A, &grid);
         } else {
             // X, row-stage coefficients (2D only), pyramid, coefficients / sort slots, reduction scratch
             const size_t shmem = ((size_t)(lgC > 0 ? 3 : 2) * R * C + S.NS + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double) + 16;

@@ -24,3 +24,20 @@ extern "C" const void* wn_kernel_wave64_transform(int kind, int np) {
 extern "C" const void* wn_kernel_wave64(int np) { return wn_kernel_wave64_transform(0, np); }
 
 extern "C" const void* wn_kernel_wave64_sparse() { return (const void*)&wn::k_sparse64<0>; }
+
+// training kernel of 1D signals of 1024 samples, one wave per example (wn_wave1d.h)
+extern "C" const void* wn_kernel_wave1d_np2();
+extern "C" const void* wn_kernel_wave1d_np4();
+extern "C" const void* wn_kernel_wave1d_np8();
+extern "C" const void* wn_kernel_wave1d_np16();
+extern "C" const void* wn_kernel_wave1d_np32();
+extern "C" const void* wn_kernel_wave1d(int np) {
+    switch (np) {
+        case 2: return wn_kernel_wave1d_np2();
+        case 4: return wn_kernel_wave1d_np4();
+        case 8: return wn_kernel_wave1d_np8();
+        case 16: return wn_kernel_wave1d_np16();
+        case 32: return wn_kernel_wave1d_np32();
+    }
+    return nullptr;
+}
