@@ -172,7 +172,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload, N),
                          "kernel": ("streamed path, all kernels of wn_train_batch" if R * C > 4096 else
-                                    "k_train64" if (R == 64 and C == 64) else "k_train"), "kernel_ms": kavg * 1e3,
+                                    "k_train64" if (R == 64 and C == 64) else
+                                    "k_train1d1024" if (R == 1024 and C == 1) else "k_train"), "kernel_ms": kavg * 1e3,
                          "algorithmic_bytes_per_launch": B * algorithmic_bytes(R, C)},
             "nonfinite": nonfinite,
             "final_filter": [float(v) for v in final_filter],

@@ -24,8 +24,9 @@ static std::vector<double> readAll(const char* path) {
     return v;
 }
 
+static std::string g_prefix;   // prepended to every dumped name
 static void dump(const char* name, const double* p, size_t n) {
-    std::printf("%s %zu", name, n);
+    std::printf("%s%s %zu", g_prefix.c_str(), name, n);
     for (size_t i = 0; i < n; i++) std::printf(" %.17g", p[i]);
     std::printf("\n");
 }
@@ -122,6 +123,66 @@ int main(int argc, char** argv) {
         dumpLogs(w);
         return 0;
     }
+    if (mode == "snapshot") {
+        // load IN, dump; save to PATTERN with NUMBER (post-increment), load that file into a second
+        // object, dump it with the prefix "re_".  No device call is made.
+        const std::string in = argv[2], pattern = argv[3];
+        const int number = std::atoi(argv[4]);
+        Wavenet w;
+        w.load(Snapshot(in));
+        dumpLogs(w);
+        Snapshot out(pattern, number);
+        double exists[2] = {(double)out.exists(), 0};
+        w.save(out++);
+        Snapshot written(pattern, number);
+        exists[1] = (double)written.exists();
+        dump("exists", exists, 2);
+        double num = out.number();
+        dump("nextNumber", &num, 1);
+        std::printf("file %s\n", written.file().c_str());
+        Wavenet w2;
+        w2.load(written);
+        g_prefix = "re_";
+        dumpLogs(w2);
+        g_prefix = "";
+        Wavenet w3(1.0, 2.0);                       // a missing file leaves the object alone
+        w3.load(Snapshot(pattern + ".missing"));
+        double kept[2] = {w3.lambda(), w3.alpha()};
+        dump("missingKept", kept, 2);
+        w3.save(Snapshot("/tmp/absolute_paths_are_refused.snap"));
+        double refused = (double)fileExists("/tmp/absolute_paths_are_refused.snap");
+        dump("absoluteWritten", &refused, 1);
+        return 0;
+    }
+    if (mode == "resume") {
+        // as "train" (one example per call), but the object is saved after `first` examples and a
+        // fresh object, loaded from that file, takes over
+        const unsigned R = std::atoi(argv[2]), C = std::atoi(argv[3]), N = std::atoi(argv[4]), E = std::atoi(argv[5]);
+        const unsigned batch = std::atoi(argv[6]);
+        const double inertia = std::atof(argv[7]);
+        const unsigned first = std::atoi(argv[8]);
+        const std::string file = argv[9];
+        std::vector<double> in = readAll(argv[10]);
+        const size_t n = (size_t)R * C;
+        Wavenet w(10.0, 1e-3);
+        w.setBatchSize(batch);
+        if (inertia > 0) { w.setInertia(inertia); w.setInertiaTimeScale(5.); }
+        if (!w.setFilter(Col(N, in.data()))) return 3;
+        for (unsigned e = 0; e < first; e++) {
+            if (!w.train(Mat(R, C, in.data() + N + e * n))) return 4;
+        }
+        w.save(Snapshot(file));
+        Wavenet v;
+        v.load(Snapshot(file));
+        for (unsigned e = first; e < E; e++) {
+            if (!v.train(Mat(R, C, in.data() + N + e * n))) return 4;
+            if (!w.train(Mat(R, C, in.data() + N + e * n))) return 4;
+        }
+        dumpLogs(v);
+        g_prefix = "straight_";
+        dumpLogs(w);
+        return 0;
+    }
     if (mode == "coach") {
         const unsigned R = std::atoi(argv[2]), C = std::atoi(argv[3]), N = std::atoi(argv[4]);
         const int events = std::atoi(argv[5]);
@@ -146,8 +207,18 @@ int main(int argc, char** argv) {
         coach.setUseSimulatedAnnealing((flags >> 2) & 1u);
         if (target > 0) coach.setTargetPrecision(target);
         if (std::getenv("WAVENET_TEST_HOST_GENERATE")) coach.setGenerateOnDevice(false);
+        if (const char* dir = std::getenv("WAVENET_TEST_SNAPSHOT_DIR")) {   // relative directory for the snapshots
+            coach.setBasedir(dir);
+            coach.setSaveSnapshots();
+        }
         if (!coach.run()) return 4;
         dumpLogs(w);
+        if (coach.saveSnapshots()) {   // what the snapshot of initialisation 0 holds
+            Wavenet v;
+            v.load(Snapshot(coach.outdir() + "snapshots/driver.%06u.snap", 0));
+            g_prefix = "snap_";
+            dumpLogs(v);
+        }
         return 0;
     }
     return 2;

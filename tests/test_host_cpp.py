@@ -143,3 +143,30 @@ def test_coach_generates_on_the_device_or_on_the_host_alike():
     host, _ = run_driver(args, [a], env={"WAVENET_TEST_HOST_GENERATE": "1"})
     assert np.array_equal(dev["filterLog"], host["filterLog"])
     assert np.array_equal(dev["costLog"], host["costLog"])
+
+
+@pytest.mark.parametrize("R,C,N,E,batch,inertia,first", [(16, 16, 4, 40, 8, 0.0, 19), (32, 1, 2, 30, 4, 0.5, 8)])
+def test_snapshot_resume(R, C, N, E, batch, inertia, first):
+    """A Wavenet object saved in the middle of a batch (pending gradients in its queue) and loaded into
+    a fresh object carries on exactly as the original does (src/Wavenet.cxx:136-178, src/Snapshot.cxx)."""
+    rng = np.random.default_rng(E + N)
+    a = F.perturbed(F.daubechies(N), 1e-2, 2)
+    X = rng.random((E, R, C))
+    with tempfile.TemporaryDirectory() as tmp:
+        out, _ = run_driver(["resume", R, C, N, E, batch, inertia, first, os.path.relpath(os.path.join(tmp, "mid.snap"))],
+                            [a] + [colmajor(x) for x in X])
+    for key in ("filterLog", "costLog", "filter", "momentum", "misc"):
+        assert np.array_equal(out[key], out["straight_" + key]), key
+    assert len(out["costLog"]) == E // batch + 1
+
+
+def test_coach_writes_snapshots():
+    """With setSaveSnapshots the final state of the initialisation lands in
+    <basedir>/<name>/snapshots/<name>.000000.snap (src/Coach.cxx:127, :277) and loads back equal."""
+    a = F.perturbed(F.daubechies(4), 1e-2, 3)
+    with tempfile.TemporaryDirectory() as tmp:
+        rel = os.path.relpath(tmp)
+        out, _ = run_driver(["coach", 16, 16, 4, 48, 1, 8, 0, 5, -1], [a], env={"WAVENET_TEST_SNAPSHOT_DIR": rel})
+        assert os.path.exists(os.path.join(tmp, "driver", "snapshots", "driver.000000.snap"))
+    for key in ("filterLog", "costLog", "filter", "momentum", "misc"):
+        assert np.array_equal(out["snap_" + key], out[key]), key

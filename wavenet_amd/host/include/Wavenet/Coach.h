@@ -1,7 +1,8 @@
 // wavenet::Coach: the training driver with the reference's configuration surface
 // (include/Wavenet/Coach.h:59-149) and the loop of Coach::run (src/Coach.cxx:71-296), feeding the
-// Wavenet object whole batches instead of single events.  Snapshots and the run README are not
-// written (file I/O is outside the accelerated path).
+// Wavenet object whole batches instead of single events.  The snapshot of each initialisation's
+// final state (outdir()/snapshots/<name>.%06u.snap, src/Coach.cxx:127, :277) is written on request
+// (setSaveSnapshots); the run README is not written.
 #ifndef WAVENET_COACH_H
 #define WAVENET_COACH_H
 
@@ -41,6 +42,9 @@ public:
     // examples are generated on the device when the generator can do that (default); off: always next()
     void setGenerateOnDevice(bool flag = true) { m_generateOnDevice = flag; }
     bool generateOnDevice() const { return m_generateOnDevice; }
+    // write outdir()/snapshots/<name>.<init, 6 digits>.snap after every initialisation (default: off)
+    void setSaveSnapshots(bool flag = true) { m_saveSnapshots = flag; }
+    bool saveSnapshots() const { return m_saveSnapshots; }
 
     /// Get method(s).
     std::string name() const { return m_name; }
@@ -78,6 +82,7 @@ private:
     Col m_initialFilter;
     std::uint64_t m_seed = 1;
     bool m_generateOnDevice = true;
+    bool m_saveSnapshots = false;
 };
 
 }  // namespace wavenet

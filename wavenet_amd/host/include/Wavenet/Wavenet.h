@@ -3,7 +3,7 @@
 // backpropagation run as HIP kernels; the object keeps the reference's host-side state (filter,
 // momentum, batch queue, filter log, cost log) and semantics.
 //
-// Not carried over: save()/load() (Snapshot text files) and everything under USE_ROOT.
+// Not carried over: everything under USE_ROOT.
 #ifndef WAVENET_WAVENET_H
 #define WAVENET_WAVENET_H
 
@@ -15,6 +15,7 @@
 #include "Wavenet/Logger.h"
 #include "Wavenet/LowpassOperator.h"
 #include "Wavenet/Matrix.h"
+#include "Wavenet/Snapshot.h"
 #include "Wavenet/Utilities.h"
 
 struct wn_context;
@@ -62,6 +63,12 @@ public:
     void setDevice(int device) { m_device = device; }
 
     void print() const;
+
+    /// Storage method(s) (src/Wavenet.cxx:136-178).
+    // Writes the object to snap.file(), creating its directory; absolute paths are refused.
+    void save(Snapshot snap) const;
+    // Reads the object back; the device side, if it exists, receives the loaded filter and momentum.
+    void load(Snapshot snap);
 
     /// High-level learning method(s).
     // One example, exactly the reference's train (src/Wavenet.cxx:184-242).
@@ -115,6 +122,9 @@ protected:
     double effectiveInertia_(unsigned steps) const;
 
 private:
+    friend Snapshot& operator<<(Snapshot& snap, const Wavenet& wavenet);
+    friend const Snapshot& operator>>(const Snapshot& snap, Wavenet& wavenet);
+
     DeviceSession& device_();
     bool checkShape_(unsigned nRows, unsigned nCols) const;
     // forward + sparsity gradient + backpropagation of `count` examples already on the device,

@@ -65,6 +65,7 @@ bool Coach::run() {
     const bool adaptive = useAdaptiveLearningRate() || useAdaptiveBatchSize();
 
     std::vector<double> staging, lambdas;
+    Snapshot snap(outdir() + "snapshots/" + m_name + ".%06u.snap", 0);                   // :127
 
     for (unsigned init = 0; init < m_numInits; init++) {
         if (m_printLevel > 0) INFO("Initialisation %d/%d", init + 1, m_numInits);
@@ -153,6 +154,7 @@ bool Coach::run() {
             }
         }
         m_wavenet->costLog().pop_back();                                                // :274
+        if (m_saveSnapshots) m_wavenet->save(snap++);                                   // :277
     }
     return true;
 }

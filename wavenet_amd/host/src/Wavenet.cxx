@@ -7,6 +7,8 @@
 #include <cstring>
 #include <string>
 
+#include <sys/stat.h>
+
 #include "wavenet_hip.h"
 
 namespace wavenet {
@@ -144,6 +146,44 @@ void Wavenet::print() const {
     std::printf("Wavenet: lambda %g, alpha %g, inertia %g (time scale %g), batch size %u, queue %zu\n", m_lambda,
                 m_alpha, m_inertia, m_inertiaTimeScale, m_batchSize, m_batchQueue.size());
     std::printf("  filter   : [%s]\n  momentum : [%s]\n", f.c_str(), p.c_str());
+}
+
+/// Storage method(s).
+void Wavenet::save(Snapshot snap) const {
+    const std::string file = snap.file();
+    DEBUG("Saving snapshot '%s'.", file.c_str());
+    if (file.substr(0, 1) == "/") {                                                     // :141-144
+        WARNING("File '%s' not accepted. Only accepting realtive paths.", file.c_str());
+        return;
+    }
+    if (snap.exists()) DEBUG("File '%s' already exists. Overwriting.", file.c_str());
+    if (file.find("/") != std::string::npos) {                                          // :150-156
+        const std::string dir = file.substr(0, file.find_last_of("/"));
+        if (!dirExists(dir)) {
+            WARNING("Directory '%s' does not exist. Creating it.", dir.c_str());
+            for (std::size_t at = dir.find('/'); ; at = dir.find('/', at + 1)) {
+                const std::string part = dir.substr(0, at);
+                if (!part.empty() && !dirExists(part)) ::mkdir(part.c_str(), 0777);
+                if (at == std::string::npos) break;
+            }
+        }
+    }
+    snap << *this;
+}
+
+void Wavenet::load(Snapshot snap) {
+    DEBUG("Loading snapshot '%s'.", snap.file().c_str());
+    if (!fileExists(snap.file())) {
+        WARNING("File '%s' doesn't exists.", snap.file().c_str());
+        return;
+    }
+    snap >> *this;
+    // the loaded taps replace whatever the device-side operators were built from
+    if (m_session && m_session->ctx && !m_filter.is_empty()) {
+        m_session->ok(wn_set_filter(m_session->ctx, m_filter.memptr(), (int)m_filter.n_elem));
+        if (m_momentum.n_elem == m_filter.n_elem)
+            m_session->ok(wn_set_momentum(m_session->ctx, m_momentum.memptr(), (int)m_momentum.n_elem));
+    }
 }
 
 bool Wavenet::checkShape_(unsigned nRows, unsigned nCols) const {
