@@ -51,6 +51,19 @@ def cpu_baseline(X, a0, lam, alpha, budget_s=15.0):
     """Times the dense CPU restatement of the reference path (oracle/, one thread) on a bounded
     sample of the same examples: Wavenet::train per example, one batch update at the end."""
     from oracle import oracle as orc  # baseline leg only
+    if max(X.shape[1], X.shape[2]) > 4096:
+        # the dense operators of a line this long cannot be held (2^19 x 2^20 doubles = 4 TiB at 2^20
+        # samples): time the banded restatement of the same arithmetic instead, and say so
+        t0 = time.perf_counter()
+        orc.band_train_batch(a0, X[:1])
+        per = time.perf_counter() - t0
+        count = int(max(1, min(len(X), budget_s / max(per, 1e-9))))
+        t0 = time.perf_counter()
+        orc.band_train_batch(a0, X[:count])
+        dt = time.perf_counter() - t0
+        return {"value": count / dt, "unit": "examples/s", "cores": 1, "kind": "port",
+                "sample": f"{count} of the benchmark's examples through the BANDED restatement (forward, Gini gradient, "
+                          f"backpropagation; the reference's dense operators would need 4 TiB at this length), {dt:.1f} s"}
     probe = 16
     w = orc.Wavenet(lam=lam, alpha=alpha)
     w.set_batch_size(1 << 30)
