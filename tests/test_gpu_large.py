@@ -176,3 +176,57 @@ def test_sparse_term_32bit_keys_against_64bit_sort(ctx, oracle, n, B):
         assert relerr(D[e], D2[e]) < 1e-12
         assert S[e] == pytest.approx(oracle.sparse_term(Y[e]), rel=1e-11)
         assert relerr(D[e], oracle.sparse_term_deriv(Y[e])) < 1e-10
+
+
+@pytest.mark.parametrize("n", [8192, 1 << 18])
+@pytest.mark.parametrize("in_place", [False, True])
+def test_sparse_term_zeros_left_out_of_the_sort(ctx, oracle, n, in_place):
+    """Exact zeros are compacted away before the sort and rank first: an all-zero example (NaN cost, as in
+    the reference), a mostly-zero one with its non-zeros at workgroup boundaries, a dense one, a single
+    non-zero coefficient, and signed zeros; errors written in place and to a separate array."""
+    import torch
+    B = 5
+    rng = np.random.default_rng(n)
+    Y = np.zeros((B, n))
+    Y[1] = np.where(rng.random(n) < 0.05, rng.standard_normal(n), 0.0)
+    Y[1, [0, 2047, 2048, 4095, 4096, n - 1]] = [3.0, -2.0, 1.0, 1.0, -1.0, 0.5]
+    Y[2] = rng.standard_normal(n)
+    Y[3, n // 2 + 1] = -4.0
+    Y[4] = np.where(rng.random(n) < 0.5, rng.standard_normal(n), -0.0)
+    dY = torch.from_numpy(Y.reshape(-1).copy()).cuda()
+    dD = dY if in_place else dev_empty(B * n).fill_(7.0)
+    dS = dev_empty(B)
+    ctx.sparse_term_deriv(dY, B, n, dD, dS)
+    torch.cuda.synchronize()
+    D = dD.cpu().numpy().reshape(B, n)
+    S = dS.cpu().numpy()
+    assert np.isnan(S[0])
+    for e in range(1, B):
+        assert S[e] == pytest.approx(oracle.sparse_term(Y[e]), rel=1e-11)
+        want = oracle.sparse_term_deriv(Y[e])
+        assert relerr(D[e], want) < 1e-10
+        assert np.all(D[e][Y[e] == 0] == 0)
+    assert S[3] == pytest.approx(1.0 / n, rel=1e-12)
+
+
+@pytest.mark.parametrize("n", [8192, 1 << 18])
+def test_sparse_term_magnitudes_outside_the_key_range(ctx, oracle, n):
+    """The sort key keeps 7 exponent bits (2^-95 ... 2^33) and the leading mantissa bits; smaller and larger
+    magnitudes share the end keys and are ordered by the exact re-ranking of equal keys, as are the
+    several coefficients per key of a dense example."""
+    import torch
+    B = 3
+    rng = np.random.default_rng(n + 1)
+    Y = rng.standard_normal((B, n))
+    Y[0, :300] = rng.standard_normal(300) * 1e-40        # below the range, few enough for the short-key path
+    Y[0, 300:500] = rng.standard_normal(200) * 1e20      # above it
+    Y[1] *= np.exp(8 * rng.standard_normal(n))           # wide but inside
+    Y[2] = 1.0 + rng.random(n) * 2.0 ** -8               # one binade, many per key
+    dY = torch.from_numpy(Y.reshape(-1)).cuda()
+    dD, dS = dev_empty(B * n), dev_empty(B)
+    ctx.sparse_term_deriv(dY, B, n, dD, dS)
+    torch.cuda.synchronize()
+    D, S = dD.cpu().numpy().reshape(B, n), dS.cpu().numpy()
+    for e in range(B):
+        assert S[e] == pytest.approx(oracle.sparse_term(Y[e]), rel=1e-11)
+        assert relerr(D[e], oracle.sparse_term_deriv(Y[e])) < 1e-10

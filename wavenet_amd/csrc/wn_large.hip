@@ -12,6 +12,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <algorithm>
+#include <vector>
 
 #include "wn_internal.h"
 
@@ -239,22 +240,119 @@ __global__ __launch_bounds__(BT) void kb_gini_delta(const unsigned* pos, const d
 // would make the counting quadratic: kb_gather_sorted notices and the caller takes the 64-bit path.
 constexpr unsigned GROUP_LIMIT = 1024;
 
-__global__ void kb_key32(const double* Y, unsigned* key, unsigned* idx, size_t total, int lgn, int magbits) {
-    for (size_t i = (size_t)blockIdx.x * BT + threadIdx.x; i < total; i += (size_t)gridDim.x * BT) {
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(Y[i]) & 0x7FFFFFFFFFFFFFFFull;
-        const unsigned ex = (unsigned)(i >> lgn);
-        key[i] = (magbits < 32 ? (ex << magbits) : 0u) | (unsigned)(bits >> (63 - magbits));
-        idx[i] = (unsigned)i;
+// Exact zeros are left out of the sort: they rank first, in index order, need no rank of their own (the
+// sign of a zero is zero) and add nothing to either sum; an example with z zeros has the ranks of its other
+// coefficients start at z + 1.  Sparse inputs leave many coefficients exactly zero (needle inputs almost
+// all of them, the 512x512 calorimeter images 15 % with a 4-tap filter), and everything from the sort to
+// the scatter shrinks with them.  The compaction keeps index order (the stable sort's tie order):
+// workgroups of CP_BLOCK elements count their non-zeros, one workgroup scans the counts, and each
+// workgroup then writes its keys behind its offset.
+//
+// Key: example number above `magbits` bits of magnitude -- 7 bits of exponent, clamped to [2^-95, 2^33),
+// and the leading mantissa bits that fit (20 for slices of 32 examples); magnitudes below the range share
+// the lowest key, those above it the highest (the map stays monotone; kb_fix_ranks orders equal keys
+// exactly).  Measured: 12 mantissa bits (24-bit keys, three radix passes instead of four) cost more in
+// kb_fix_ranks than the pass saves -- smooth 2^20-sample signals put dozens of coefficients on each key.
+constexpr int KEY_E0 = 1023 - 95;
+constexpr int CP_ITEMS = 8, CP_BLOCK = BT * CP_ITEMS;
+
+__global__ __launch_bounds__(BT) void kb_count_nonzero(const double* Y, unsigned* counts) {
+    __shared__ unsigned wsum[BT / 64];
+    const size_t base = (size_t)blockIdx.x * CP_BLOCK;
+    unsigned c = 0;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; k++) c += (Y[base + (size_t)k * BT + threadIdx.x] != 0.0) ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int w = 0; w < BT / 64; w++) t += wsum[w];
+        counts[blockIdx.x] = t;
+    }
+}
+// counts[b] -> number of non-zeros before workgroup b (in place); segs[2e], segs[2e+1] = first sorted
+// position and number of non-zeros of example e (bpe workgroups each); *total = all of them.  One workgroup.
+__global__ __launch_bounds__(BT) void kb_scan_counts(unsigned* counts, int nblocks, int bpe, int Bs, unsigned* segs, unsigned* total) {
+    __shared__ unsigned part[BT];
+    const int tid = threadIdx.x;
+    const int per = (nblocks + BT - 1) / BT;
+    const int b0 = tid * per, b1 = min(b0 + per, nblocks);
+    unsigned sum = 0;
+    for (int b = b0; b < b1; b++) sum += counts[b];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned run = 0;
+        for (int t = 0; t < BT; t++) { const unsigned c = part[t]; part[t] = run; run += c; }
+        *total = run;
+    }
+    __syncthreads();
+    unsigned run = part[tid];
+    for (int b = b0; b < b1; b++) { const unsigned c = counts[b]; counts[b] = run; run += c; }
+    __syncthreads();
+    __threadfence_block();
+    for (int e = tid; e < Bs; e += BT) {
+        const unsigned first = counts[e * bpe];
+        const unsigned next = (e + 1 < Bs) ? counts[(e + 1) * bpe] : *total;
+        segs[2 * e] = first;
+        segs[2 * e + 1] = next - first;
+    }
+}
+// key / idx of the non-zero coefficients, in index order, behind the workgroup's offset
+__device__ __forceinline__ unsigned magnitude_key(unsigned long long bits, int magbits) {
+    const int e = (int)(bits >> 52) - KEY_E0;
+    const int mb = magbits - 7;
+    if (e < 0) return 0u;
+    if (e > 127) return 0xFFFFFFFFu >> (32 - magbits);
+    return ((unsigned)e << mb) | ((unsigned)(bits >> (52 - mb)) & ((1u << mb) - 1u));
+}
+__global__ __launch_bounds__(BT) void kb_key32_compact(const double* Y, const unsigned* starts, unsigned* key, unsigned* idx,
+                                                       int lgn, int magbits) {
+    __shared__ unsigned wtot[CP_ITEMS * (BT / 64)];
+    const size_t base = (size_t)blockIdx.x * CP_BLOCK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long bits[CP_ITEMS];
+    unsigned before[CP_ITEMS];
+    unsigned nzmask = 0;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; k++) {
+        const double v = Y[base + (size_t)k * BT + tid];
+        bits[k] = (unsigned long long)__double_as_longlong(v) & 0x7FFFFFFFFFFFFFFFull;
+        const bool nz = (v != 0.0);
+        const unsigned long long ballot = __ballot(nz);
+        before[k] = (unsigned)__popcll(ballot & ((1ull << lane) - 1ull));
+        if (lane == 0) wtot[k * (BT / 64) + wave] = (unsigned)__popcll(ballot);
+        nzmask |= nz ? (1u << k) : 0u;
+    }
+    __syncthreads();
+    unsigned run = starts[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; k++) {
+        unsigned mine = 0;
+#pragma unroll
+        for (int w = 0; w < BT / 64; w++) {
+            if (w == wave) mine = run;
+            run += wtot[k * (BT / 64) + w];
+        }
+        if (nzmask & (1u << k)) {
+            const size_t i = base + (size_t)k * BT + tid;
+            const unsigned p = mine + before[k];
+            const unsigned ex = (unsigned)(i >> lgn);
+            key[p] = (magbits < 32 ? (ex << magbits) : 0u) | magnitude_key(bits[k], magbits);
+            idx[p] = (unsigned)i;
+        }
     }
 }
 // F[p] = coefficient at sorted position p; *flag set when a group of non-zero keys is too long
 __global__ void kb_gather_sorted(const double* Y, const unsigned* key, const unsigned* idx, double* F, size_t total,
-                                 unsigned magmask, unsigned* flag) {
+                                 unsigned* flag) {
     bool over = false;
     for (size_t p = (size_t)blockIdx.x * BT + threadIdx.x; p < total; p += (size_t)gridDim.x * BT) {
         F[p] = Y[idx[p]];
         const unsigned k = key[p];
-        if ((k & magmask) != 0 && p + GROUP_LIMIT < total && key[p + GROUP_LIMIT] == k) over = true;
+        if (p + GROUP_LIMIT < total && key[p + GROUP_LIMIT] == k) over = true;
     }
     if (over) *flag = 1u;
 }
@@ -264,17 +362,17 @@ __global__ void kb_gather_sorted(const double* Y, const unsigned* key, const uns
 // reaches past the staged range (rare) is counted from global memory instead.
 constexpr int FIX_TILE = 2048, FIX_HALO = 32;
 __global__ __launch_bounds__(BT) void kb_fix_ranks(const unsigned* key, const unsigned* idx, const double* F, unsigned n,
-                                                   unsigned magmask, unsigned* rank, double* part) {
+                                                   const unsigned* segs, unsigned* rank, double* part) {
     __shared__ double red[2 * (BT / 64)];
     __shared__ double la[FIX_TILE + 2 * FIX_HALO];
     __shared__ unsigned lk[FIX_TILE + 2 * FIX_HALO], li[FIX_TILE + 2 * FIX_HALO];
-    const size_t exstart = (size_t)blockIdx.y * n, exend = exstart + n;
-    const unsigned span = n / gridDim.x;   // a multiple of FIX_TILE or a power of two below it
-    const size_t p0 = exstart + (size_t)blockIdx.x * span;
-    const unsigned tile = span < (unsigned)FIX_TILE ? span : (unsigned)FIX_TILE;
+    // the example's non-zero coefficients in sorted order; its zeros hold the ranks 1 .. zeros
+    const size_t exstart = segs[2 * blockIdx.y], exend = exstart + segs[2 * blockIdx.y + 1];
+    const unsigned zeros = n - segs[2 * blockIdx.y + 1];
     const int tid = threadIdx.x;
     double f = 0, a = 0;
-    for (size_t t0 = p0; t0 < p0 + span; t0 += tile) {
+    for (size_t t0 = exstart + (size_t)blockIdx.x * FIX_TILE; t0 < exend; t0 += (size_t)gridDim.x * FIX_TILE) {
+        const size_t tile = (exend - t0 < (size_t)FIX_TILE) ? exend - t0 : (size_t)FIX_TILE;
         const size_t lo = (t0 >= exstart + FIX_HALO) ? t0 - FIX_HALO : exstart;
         const size_t hi = (t0 + tile + FIX_HALO <= exend) ? t0 + tile + FIX_HALO : exend;
         const int cnt = (int)(hi - lo);
@@ -289,10 +387,8 @@ __global__ __launch_bounds__(BT) void kb_fix_ranks(const unsigned* key, const un
             const int l = (int)(p - lo);
             const unsigned k = lk[l];
             const double av = la[l];
-            unsigned rk = (unsigned)(p - exstart) + 1u;
-            if ((k & magmask) == 0 && av == 0.0) {
-                rk = 0;  // never used: the sign of a zero is zero
-            } else if ((l > 0 && lk[l - 1] == k) || (l + 1 < cnt && lk[l + 1] == k)) {
+            unsigned rk = zeros + (unsigned)(p - exstart) + 1u;
+            if ((l > 0 && lk[l - 1] == k) || (l + 1 < cnt && lk[l + 1] == k)) {
                 int gs = l;
                 while (gs > 0 && lk[gs - 1] == k) gs--;
                 int ge = l + 1;
@@ -301,7 +397,7 @@ __global__ __launch_bounds__(BT) void kb_fix_ranks(const unsigned* key, const un
                 unsigned below = 0;
                 if ((gs > 0 || lo == exstart) && (ge < cnt || hi == exend)) {
                     for (int q = gs; q < ge; q++) below += (la[q] < av || (la[q] == av && li[q] < me)) ? 1u : 0u;
-                    rk = (unsigned)(lo + gs - exstart) + below + 1u;
+                    rk = zeros + (unsigned)(lo + gs - exstart) + below + 1u;
                 } else {  // the group reaches past the staged range
                     size_t g0 = p;
                     while (g0 > exstart && key[g0 - 1] == k) g0--;
@@ -309,7 +405,7 @@ __global__ __launch_bounds__(BT) void kb_fix_ranks(const unsigned* key, const un
                         const double aq = __builtin_fabs(F[q]);
                         below += (aq < av || (aq == av && idx[q] < me)) ? 1u : 0u;
                     }
-                    rk = (unsigned)(g0 - exstart) + below + 1u;
+                    rk = zeros + (unsigned)(g0 - exstart) + below + 1u;
                 }
             }
             rank[p] = rk;
@@ -330,11 +426,12 @@ __global__ __launch_bounds__(BT) void kb_fix_ranks(const unsigned* key, const un
 }
 // delta of the element at sorted position p, written to its home
 __global__ __launch_bounds__(BT) void kb_delta_scatter(const unsigned* rank, const unsigned* idx, const double* F, double* Dout,
-                                                       const double* fg, unsigned n) {
-    const size_t off = (size_t)blockIdx.y * n;
+                                                       const double* fg, unsigned n, const unsigned* segs) {
+    const size_t off = segs[2 * blockIdx.y];
+    const unsigned count = segs[2 * blockIdx.y + 1];
     const double f = fg[2 * blockIdx.y], g = fg[2 * blockIdx.y + 1];
     const double inv_g2 = 1.0 / (g * g);
-    for (unsigned p = blockIdx.x * BT + threadIdx.x; p < n; p += gridDim.x * BT) {
+    for (unsigned p = blockIdx.x * BT + threadIdx.x; p < count; p += gridDim.x * BT) {
         const double sg = sign_ref(F[off + p]);
         const double df = (2.0 * (double)rank[off + p] - (double)n - 1.0) * sg;
         Dout[idx[off + p]] = -(df * g - f * ((double)n * sg)) * inv_g2;
@@ -448,52 +545,68 @@ int gini_big(wn_context* ctx, const double* Y, double* D, int B, size_t n, doubl
     return WN_OK;
 }
 
-// Gini term and gradient of a chunk: the 32-bit-key path when it applies, else gini_big.  The chunk is
-// sorted in slices of few enough examples that the example number leaves about lg(n) - 2 mantissa
-// bits in the key: groups of equal keys then hold about one element on smooth data.
+// Gini term and gradient of a chunk: the short-key path when it applies, else gini_big.  The chunk is
+// sorted in slices of at most 2^23 coefficients (32 examples of 512x512, 8 signals of 2^20 samples).
 int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB,
-               unsigned* idxA, unsigned* idxB, double* gpart, double* fg, double* S_e, void* sort_tmp,
+               unsigned* idxA, unsigned* idxB, unsigned* cnt, double* gpart, double* fg, double* S_e, void* sort_tmp,
                size_t sort_tmp_bytes) {
     int lgn = 0;
     while (((size_t)1 << lgn) < n) lgn++;
-    const int exbits_max = 23 - lgn;   // 32 - exbits >= 11 exponent bits + (lgn - 2) mantissa bits
+    const int exbits_max = 23 - lgn;   // slices of 2^23 coefficients
     if (exbits_max < 0 || ctx->exact_sort)
         return gini_big(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, gpart, fg, S_e, sort_tmp, sort_tmp_bytes);
     const int slice = std::min(B, 1 << exbits_max);
     int exbits = 0;
     while ((1 << exbits) < slice) exbits++;
     const int magbits = 32 - exbits;
-    const unsigned magmask = magbits >= 32 ? 0xFFFFFFFFu : ((1u << magbits) - 1u);
     hipStream_t st = ctx->stream;
-    unsigned* flag = idxA;   // the first slice's idxA is free once its sort has run
-    for (int e0 = 0; e0 < B; e0 += slice) {
+    // cnt: per workgroup of CP_BLOCK coefficients the number of non-zeros before it (within its slice),
+    // then per example {first sorted position, non-zeros}, then per slice the number of non-zeros, then a flag
+    const int bpe = (int)(n / CP_BLOCK);                 // n is a power of two >= 8192
+    unsigned* segs = cnt + (size_t)B * bpe;
+    unsigned* totals = segs + 2 * (size_t)B;
+    const int nslices = (B + slice - 1) / slice;
+    unsigned* flag = totals + nslices;
+    for (int e0 = 0, sl = 0; e0 < B; e0 += slice, sl++) {
         const int Bs = std::min(slice, B - e0);
-        const size_t off = (size_t)e0 * n, total = (size_t)Bs * n;
-        const unsigned blocks = (unsigned)std::min<size_t>((total + BT - 1) / BT, 65536);
+        unsigned* counts = cnt + (size_t)e0 * bpe;
+        hipLaunchKernelGGL(kb_count_nonzero, dim3(Bs * bpe), dim3(BT), 0, st, Y + (size_t)e0 * n, counts);
+        hipLaunchKernelGGL(kb_scan_counts, dim3(1), dim3(BT), 0, st, counts, Bs * bpe, bpe, Bs, segs + 2 * (size_t)e0, totals + sl);
+    }
+    WN_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(unsigned), st));
+    std::vector<unsigned> nonzero(nslices);
+    WN_HIP(ctx, hipMemcpyAsync(nonzero.data(), totals, nslices * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    WN_HIP(ctx, hipStreamSynchronize(st));   // the sorts take their sizes from the host
+    for (int e0 = 0, sl = 0; e0 < B; e0 += slice, sl++) {
+        const int Bs = std::min(slice, B - e0);
+        const size_t off = (size_t)e0 * n, total = nonzero[sl];
+        if (total == 0) continue;
         unsigned* keyA = reinterpret_cast<unsigned*>(keysA + off);   // two 32-bit arrays in the slice of keysA
-        unsigned* keyB = keyA + total;
-        hipLaunchKernelGGL(kb_key32, dim3(blocks), dim3(BT), 0, st, Y + off, keyA, idxA + off, total, lgn, magbits);
+        unsigned* keyB = keyA + (size_t)Bs * n;
+        hipLaunchKernelGGL(kb_key32_compact, dim3(Bs * bpe), dim3(BT), 0, st, Y + off, cnt + (size_t)e0 * bpe, keyA, idxA + off, lgn, magbits);
         WN_HIP(ctx, rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keyA, keyB, idxA + off, idxB + off, total, 0, 32, st));
-        if (e0 == 0) WN_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(unsigned), st));
-        hipLaunchKernelGGL(kb_gather_sorted, dim3(blocks), dim3(BT), 0, st, Y + off, keyB, idxB + off, keysB + off, total, magmask, flag);
+        const unsigned blocks = (unsigned)std::min<size_t>((total + BT - 1) / BT, 65536);
+        hipLaunchKernelGGL(kb_gather_sorted, dim3(blocks), dim3(BT), 0, st, Y + off, keyB, idxB + off, keysB + off, total, flag);
     }
     unsigned over = 0;
     WN_HIP(ctx, hipMemcpyAsync(&over, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     WN_HIP(ctx, hipStreamSynchronize(st));
     if (over) return gini_big(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, gpart, fg, S_e, sort_tmp, sort_tmp_bytes);
-    const int gx = (int)std::min<size_t>(n / BT, GXMAX);   // n is a power of two >= 8192: gx divides it
+    const int gx = (int)std::min<size_t>(n / FIX_TILE, GXMAX);
+    // the zeros' errors are zero: in place they already are, elsewhere they are written here
+    if (D && D != Y) WN_HIP(ctx, hipMemsetAsync(D, 0, (size_t)B * n * sizeof(double), st));
     for (int e0 = 0; e0 < B; e0 += slice) {
         const int Bs = std::min(slice, B - e0);
-        const size_t off = (size_t)e0 * n, total = (size_t)Bs * n;
+        const size_t off = (size_t)e0 * n;
         unsigned* keyA = reinterpret_cast<unsigned*>(keysA + off);
-        unsigned* keyB = keyA + total;
+        unsigned* keyB = keyA + (size_t)Bs * n;
         unsigned* rank = keyA;
-        hipLaunchKernelGGL(kb_fix_ranks, dim3(gx, Bs), dim3(BT), 0, st, keyB, idxB + off, keysB + off, (unsigned)n, magmask, rank,
-                           gpart + (size_t)e0 * GXMAX * 2);
+        hipLaunchKernelGGL(kb_fix_ranks, dim3(gx, Bs), dim3(BT), 0, st, keyB, idxB + off, keysB + off, (unsigned)n,
+                           segs + 2 * (size_t)e0, rank, gpart + (size_t)e0 * GXMAX * 2);
         hipLaunchKernelGGL(kb_gini_finish, dim3((Bs + BT - 1) / BT), dim3(BT), 0, st, gpart + (size_t)e0 * GXMAX * 2, Bs, gx,
                            (unsigned)n, fg + 2 * (size_t)e0, S_e ? S_e + e0 : nullptr);
         if (D) hipLaunchKernelGGL(kb_delta_scatter, grid_for((int)std::min<size_t>(n, 1u << 30), Bs), dim3(BT), 0, st, rank,
-                                  idxB + off, keysB + off, D + off, fg + 2 * (size_t)e0, (unsigned)n);
+                                  idxB + off, keysB + off, D + off, fg + 2 * (size_t)e0, (unsigned)n, segs + 2 * (size_t)e0);
     }
     WN_HIP(ctx, hipGetLastError());
     return WN_OK;
@@ -512,7 +625,7 @@ struct Plan {
     int Bc;                 // examples per chunk
     size_t n;
     double *Prow, *Y1, *Pcol, *YD, *A, *Bb, *gpart, *fg, *partial, *grad_e, *S_e;
-    unsigned *idxA, *idxB;
+    unsigned *idxA, *idxB, *cnt;
     void* sort_tmp;
     size_t sort_tmp_bytes;
 };
@@ -537,6 +650,7 @@ int make_plan(wn_context* ctx, int B, size_t n, int NP, int N, Plan* pl) {
         pl->Bb = c.take<double>(Bc * n);
         pl->idxA = c.take<unsigned>(Bc * n);
         pl->idxB = c.take<unsigned>(Bc * n);
+        pl->cnt = c.take<unsigned>(Bc * (n / CP_BLOCK + 1) + 3 * Bc + 64);
         pl->gpart = c.take<double>(Bc * GXMAX * 2);
         pl->fg = c.take<double>(Bc * 2);
         pl->partial = c.take<double>(Bc * GXMAX * 2 * NP);
@@ -576,7 +690,7 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         if (forward_only) continue;
         double* S_e = S ? S + e0 : pl.S_e;
         double* grad_e = grad ? grad + (size_t)e0 * N : pl.grad_e;
-        if ((rc = gini_large(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes))) return rc;
+        if ((rc = gini_large(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes))) return rc;
         WN_HIP(ctx, hipMemsetAsync(pl.partial, 0, (size_t)Bc * GXMAX * 2 * NP * sizeof(double), st));
         const double* D1 = nullptr;
         if ((rc = bwd_pass_big<NP>(ctx, YD, Y1, Pcol, pl.A, pl.Bb, Bc, n, cg, lgC > 0, pl.partial, &D1))) return rc;
@@ -678,7 +792,7 @@ int large_sparse(wn_context* ctx, const double* Y, int B, long long n, double* D
         const int Bc = std::min(pl.Bc, B - e0);
         const size_t o = (size_t)e0 * n;
         if ((rc = gini_large(ctx, Y + o, Delta ? Delta + o : nullptr, Bc, (size_t)n, pl.A, pl.Bb, pl.idxA, pl.idxB,
-                           pl.gpart, pl.fg, S ? S + e0 : nullptr, pl.sort_tmp, pl.sort_tmp_bytes)))
+                           pl.cnt, pl.gpart, pl.fg, S ? S + e0 : nullptr, pl.sort_tmp, pl.sort_tmp_bytes)))
             return rc;
     }
     return WN_OK;
