@@ -141,6 +141,64 @@ __global__ __launch_bounds__(BT) void kb_prop_level(const double* __restrict__ l
     }
 }
 
+// kb_grad_level and kb_prop_level of one level in one pass over lp / hp: the errors are read from HBM once.
+template <int NP>
+__global__ __launch_bounds__(BT) void kb_bwd_level(const double* __restrict__ lp, const double* __restrict__ hp,
+                                                   const double* __restrict__ act, double* __restrict__ out, size_t xs, Geom g,
+                                                   int lgLen, const FilterDev* filt, double* partial) {
+    __shared__ double red[(BT / 64) * 2 * NP];
+    double a[NP], b[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    double gL[NP], gH[NP];
+#pragma unroll
+    for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
+    constexpr int S = NP / 2;
+    constexpr int JE = S & 1, JO = (S + 1) & 1;
+    constexpr int CE = (JE - S) / 2, CO = (1 + JO - S) / 2;
+    const size_t off = (size_t)blockIdx.y * xs;
+    const int W = 1 << (g.lgNL + lgLen), amask = (2 << lgLen) - 1, rmask = (1 << lgLen) - 1;
+    for (int w = blockIdx.x * BT + threadIdx.x; w < W; w += gridDim.x * BT) {
+        int line, r;
+        decode(w, g.lgNL, lgLen, g.lanesOnLines, line, r);
+        const size_t lo = off + (size_t)line * g.ls;
+        const double dl = lp[lo + (size_t)r * g.es];
+        const double dh = hp[lo + (size_t)r * g.es];
+        const int base = 2 * r + NP / 2;
+#pragma unroll
+        for (int u = 0; u < NP; u++) {
+            const double v = act[lo + (size_t)((base - u) & amask) * g.es];
+            gL[u] = __builtin_fma(dl, v, gL[u]);
+            gH[u] = __builtin_fma(dh, v, gH[u]);
+        }
+        double se = 0, so = 0;
+#pragma unroll
+        for (int i = 0; i < NP / 2; i++) {
+            const size_t re = lo + (size_t)((r + i + CE) & rmask) * g.es;
+            const size_t ro = lo + (size_t)((r + i + CO) & rmask) * g.es;
+            se = __builtin_fma(a[JE + 2 * i], lp[re], se);
+            se = __builtin_fma(b[JE + 2 * i], hp[re], se);
+            so = __builtin_fma(a[JO + 2 * i], lp[ro], so);
+            so = __builtin_fma(b[JO + 2 * i], hp[ro], so);
+        }
+        out[lo + (size_t)(2 * r) * g.es] = se;
+        out[lo + (size_t)(2 * r + 1) * g.es] = so;
+    }
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < NP; u++) {
+        const double sl = wave_sum(gL[u]), sh = wave_sum(gH[u]);
+        if ((tid & 63) == 0) { red[(tid >> 6) * 2 * NP + u] = sl; red[(tid >> 6) * 2 * NP + NP + u] = sh; }
+    }
+    __syncthreads();
+    if (tid < 2 * NP) {
+        double s = 0;
+#pragma unroll
+        for (int wv = 0; wv < BT / 64; wv++) s += red[wv * 2 * NP + tid];
+        partial[((size_t)blockIdx.y * GXMAX + blockIdx.x) * 2 * NP + tid] += s;
+    }
+}
+
 // Per-example gradient from the per-workgroup window sums: tap k collects gL[k] and (-1)^(N-1-k) gH[N-1-k].
 __global__ void kb_grad_finish(const double* partial, int NP, const FilterDev* filt, double* grad_e) {
     const int ex = blockIdx.x, kp = threadIdx.x;
@@ -499,6 +557,15 @@ int bwd_pass_big(wn_context* ctx, const double* coef, const double* in, const do
     double* dst = pingA;
     for (int i = 0; i < g.lgLen; i++) {
         const double* hp = coef + (size_t)(1 << i) * g.es;
+        const bool propagate = (i != g.lgLen - 1 || lastPropagate);
+        if (partial && propagate) {
+            const double* act = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i) * g.es;
+            hipLaunchKernelGGL(kb_bwd_level<NP>, grid_for(1 << (g.lgNL + i), B, GXMAX), dim3(BT), 0, st, lp, hp, act, dst, n, g, i,
+                               ctx->dfilt, partial);
+            lp = dst;
+            dst = (dst == pingA) ? pingB : pingA;
+            continue;
+        }
         if (partial) {
             const double* act = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i) * g.es;
             hipLaunchKernelGGL(kb_grad_level<NP>, grid_for(1 << (g.lgNL + i), B, GXMAX), dim3(BT), 0, st, lp, hp, act, n, g, i, partial);
