@@ -27,7 +27,7 @@ WORKLOADS = {
     # name: (R, C, per-GPU batch, default taps, generator)
     "2d64": (64, 64, 4096, 4, "calorimeter"),
     "1d1024": (1024, 1, 4096, 16, "bumps"),
-    "2d512": (512, 512, 256, 4, "calorimeter"),     # streamed path; per-GPU batch reduced from 2048 (workspace: 14 arrays of batch x n)
+    "2d512": (512, 512, 2048, 4, "calorimeter"),    # streamed path; 16384 images over 8 GPUs
     "1d1m": (1 << 20, 1, 8, 32, "bumps"),           # streamed path, 8 signals per GPU
 }
 
@@ -193,7 +193,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             if X is None:
-                X = make_inputs(gen, min(2 * B, 16384), R, C, seed=1000 + rank)   # the same sequence of examples, on the host
+                # the same sequence of examples, on the host: no more of them than the sample can use
+                X = make_inputs(gen, min(2 * B, 16384, max(64, (1 << 24) // (R * C))), R, C, seed=1000 + rank)
             out["cpu_baseline"] = cpu_baseline(X, a0, lam, alpha)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)

@@ -619,7 +619,7 @@ int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, dou
                size_t sort_tmp_bytes) {
     int lgn = 0;
     while (((size_t)1 << lgn) < n) lgn++;
-    const int exbits_max = 23 - lgn;   // slices of 2^23 coefficients
+    const int exbits_max = 26 - lgn;   // slices of 2^26 coefficients
     if (exbits_max < 0 || ctx->exact_sort)
         return gini_big(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, gpart, fg, S_e, sort_tmp, sort_tmp_bytes);
     const int slice = std::min(B, 1 << exbits_max);
