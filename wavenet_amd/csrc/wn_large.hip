@@ -293,9 +293,9 @@ __global__ __launch_bounds__(BT) void kb_gini_delta(const unsigned* pos, const d
 // One radix sort of 32-bit keys instead of a 64-bit and a segment sort: key = example number in the top
 // bits, then as many leading bits of the magnitude (exponent first) as fit.  Positions whose keys are
 // equal form a group -- same example, magnitudes equal in those leading bits -- that the stable sort
-// leaves in index order; kb_fix_ranks puts each group in (exact magnitude, index) order by counting.
-// Groups of exact zeros need no order (rank times sign(0) is 0).  A group longer than GROUP_LIMIT
-// would make the counting quadratic: kb_gather_sorted notices and the caller takes the 64-bit path.
+// leaves in index order; kb_rank_home puts each group in (exact magnitude, index) order by counting.
+// A group longer than GROUP_LIMIT would make the counting quadratic: kb_rank_home notices and the caller
+// takes the 64-bit path.
 constexpr unsigned GROUP_LIMIT = 1024;
 
 // Exact zeros are left out of the sort: they rank first, in index order, need no rank of their own (the
@@ -308,9 +308,9 @@ constexpr unsigned GROUP_LIMIT = 1024;
 //
 // Key: example number above `magbits` bits of magnitude -- 7 bits of exponent, clamped to [2^-95, 2^33),
 // and the leading mantissa bits that fit (20 for slices of 32 examples); magnitudes below the range share
-// the lowest key, those above it the highest (the map stays monotone; kb_fix_ranks orders equal keys
+// the lowest key, those above it the highest (the map stays monotone; kb_rank_home orders equal keys
 // exactly).  Measured: 12 mantissa bits (24-bit keys, three radix passes instead of four) cost more in
-// kb_fix_ranks than the pass saves -- smooth 2^20-sample signals put dozens of coefficients on each key.
+// the re-ranking of equal keys than the pass saves -- smooth 2^20-sample signals put dozens of coefficients on each key.
 constexpr int KEY_E0 = 1023 - 95;
 constexpr int CP_ITEMS = 8, CP_BLOCK = BT * CP_ITEMS;
 
@@ -403,33 +403,31 @@ __global__ __launch_bounds__(BT) void kb_key32_compact(const double* Y, const un
         }
     }
 }
-// F[p] = coefficient at sorted position p; *flag set when a group of non-zero keys is too long
-__global__ void kb_gather_sorted(const double* Y, const unsigned* key, const unsigned* idx, double* F, size_t total,
-                                 unsigned* flag) {
-    bool over = false;
-    for (size_t p = (size_t)blockIdx.x * BT + threadIdx.x; p < total; p += (size_t)gridDim.x * BT) {
-        F[p] = Y[idx[p]];
-        const unsigned k = key[p];
-        if (p + GROUP_LIMIT < total && key[p + GROUP_LIMIT] == k) over = true;
-    }
-    if (over) *flag = 1u;
-}
-// rank[p] (1-based, within the example) of the element at sorted position p, and the example's partial
-// sums: part[(example * GXMAX + workgroup) * 2 + {0,1}] = partial f, partial sum |c|.  grid (GXMAX, B).
-// The workgroup stages tiles of FIX_TILE positions plus FIX_HALO on either side in LDS; a group that
-// reaches past the staged range (rare) is counted from global memory instead.
-constexpr int FIX_TILE = 2048, FIX_HALO = 32;
-__global__ __launch_bounds__(BT) void kb_fix_ranks(const unsigned* key, const unsigned* idx, const double* F, unsigned n,
-                                                   const unsigned* segs, unsigned* rank, double* part) {
-    __shared__ double red[2 * (BT / 64)];
+constexpr int FIX_TILE = 2048, FIX_HALO = 32;   // sorted positions staged in LDS per step, and on either side
+
+// ---- ranks written home -----------------------------------------------------------------------------------
+// The sorted order is only read, never materialised as values: kb_rank_home walks the sorted (key, position)
+// pairs of an example and writes each coefficient's rank to its home position (one 4-byte scatter).  A key
+// that differs from both neighbours fixes the rank by itself; the members of a group of equal keys fetch
+// their magnitudes (the only gathers) and are ordered exactly by (magnitude, index).  A group longer than
+// GROUP_LIMIT sets *flag instead (the caller then takes the 64-bit path).  The sums and the errors are then
+// plain streaming passes over the coefficients in home order (kb_sums_home, kb_delta_home); the rank stored
+// at an exact zero is never written and never matters (it is multiplied by |c| = 0 or sign(0) = 0).
+// 1D grid of gx * (examples rounded up to 8) workgroups: consecutive workgroups go to consecutive XCDs, so
+// workgroup L works on example (L / 8 / gx) * 8 + L % 8 -- all gx workgroups of an example share one XCD,
+// whose L2 then collects the example's scattered ranks (1 MB at 512x512) into whole lines.
+__global__ __launch_bounds__(BT) void kb_rank_home(const unsigned* key, const unsigned* idx, const double* Y, unsigned n,
+                                                   const unsigned* segs, unsigned* rank, unsigned* flag, int gx, int B) {
     __shared__ double la[FIX_TILE + 2 * FIX_HALO];
     __shared__ unsigned lk[FIX_TILE + 2 * FIX_HALO], li[FIX_TILE + 2 * FIX_HALO];
-    // the example's non-zero coefficients in sorted order; its zeros hold the ranks 1 .. zeros
-    const size_t exstart = segs[2 * blockIdx.y], exend = exstart + segs[2 * blockIdx.y + 1];
-    const unsigned zeros = n - segs[2 * blockIdx.y + 1];
+    const int slot = blockIdx.x >> 3;
+    const int ex = (slot / gx) * 8 + (blockIdx.x & 7), bx = slot % gx;
+    if (ex >= B) return;
+    const size_t exstart = segs[2 * ex], exend = exstart + segs[2 * ex + 1];
+    const unsigned zeros = n - segs[2 * ex + 1];
     const int tid = threadIdx.x;
-    double f = 0, a = 0;
-    for (size_t t0 = exstart + (size_t)blockIdx.x * FIX_TILE; t0 < exend; t0 += (size_t)gridDim.x * FIX_TILE) {
+    bool over = false;
+    for (size_t t0 = exstart + (size_t)bx * FIX_TILE; t0 < exend; t0 += (size_t)gx * FIX_TILE) {
         const size_t tile = (exend - t0 < (size_t)FIX_TILE) ? exend - t0 : (size_t)FIX_TILE;
         const size_t lo = (t0 >= exstart + FIX_HALO) ? t0 - FIX_HALO : exstart;
         const size_t hi = (t0 + tile + FIX_HALO <= exend) ? t0 + tile + FIX_HALO : exend;
@@ -437,43 +435,67 @@ __global__ __launch_bounds__(BT) void kb_fix_ranks(const unsigned* key, const un
         __syncthreads();
         for (int l = tid; l < cnt; l += BT) {
             lk[l] = key[lo + l];
-            la[l] = __builtin_fabs(F[lo + l]);
             li[l] = idx[lo + l];
+        }
+        __syncthreads();
+        for (int l = tid; l < cnt; l += BT) {   // magnitudes of group members only
+            const unsigned k = lk[l];
+            if ((l > 0 && lk[l - 1] == k) || (l + 1 < cnt && lk[l + 1] == k)) la[l] = __builtin_fabs(Y[li[l]]);
         }
         __syncthreads();
         for (size_t p = t0 + tid; p < t0 + tile; p += BT) {
             const int l = (int)(p - lo);
             const unsigned k = lk[l];
-            const double av = la[l];
+            const unsigned me = li[l];
             unsigned rk = zeros + (unsigned)(p - exstart) + 1u;
             if ((l > 0 && lk[l - 1] == k) || (l + 1 < cnt && lk[l + 1] == k)) {
+                const double av = la[l];
                 int gs = l;
                 while (gs > 0 && lk[gs - 1] == k) gs--;
                 int ge = l + 1;
                 while (ge < cnt && lk[ge] == k) ge++;
-                const unsigned me = li[l];
                 unsigned below = 0;
                 if ((gs > 0 || lo == exstart) && (ge < cnt || hi == exend)) {
-                    for (int q = gs; q < ge; q++) below += (la[q] < av || (la[q] == av && li[q] < me)) ? 1u : 0u;
+                    if ((unsigned)(ge - gs) > GROUP_LIMIT) {
+                        over = true;
+                    } else {
+                        for (int q = gs; q < ge; q++) below += (la[q] < av || (la[q] == av && li[q] < me)) ? 1u : 0u;
+                    }
                     rk = zeros + (unsigned)(lo + gs - exstart) + below + 1u;
                 } else {  // the group reaches past the staged range
                     size_t g0 = p;
-                    while (g0 > exstart && key[g0 - 1] == k) g0--;
-                    for (size_t q = g0; q < exend && key[q] == k; q++) {
-                        const double aq = __builtin_fabs(F[q]);
+                    while (g0 > exstart && key[g0 - 1] == k && p - g0 <= GROUP_LIMIT) g0--;
+                    size_t q = g0;
+                    for (; q < exend && key[q] == k && q - g0 <= GROUP_LIMIT; q++) {
+                        const double aq = __builtin_fabs(Y[idx[q]]);
                         below += (aq < av || (aq == av && idx[q] < me)) ? 1u : 0u;
                     }
+                    if (q - g0 > GROUP_LIMIT) over = true;
                     rk = zeros + (unsigned)(g0 - exstart) + below + 1u;
                 }
             }
-            rank[p] = rk;
-            f = __builtin_fma(2.0 * (double)rk - (double)n - 1.0, av, f);
+            rank[me] = rk;
+        }
+    }
+    if (over) *flag = 1u;
+}
+// part[(example * GXMAX + workgroup) * 2 + {0,1}] = partial f, partial sum |c|, over home positions
+__global__ __launch_bounds__(BT) void kb_sums_home(const double* Y, const unsigned* rank, unsigned n, double* part) {
+    __shared__ double red[2 * (BT / 64)];
+    const size_t off = (size_t)blockIdx.y * n;
+    const unsigned span = n / gridDim.x;                  // gridDim.x divides n
+    const unsigned j0 = blockIdx.x * span;
+    double f = 0, a = 0;
+    for (unsigned j = j0 + threadIdx.x; j < j0 + span; j += BT) {
+        const double av = __builtin_fabs(Y[off + j]);
+        if (av != 0.0) {                                   // also true for NaN
+            f = __builtin_fma(2.0 * (double)rank[off + j] - (double)n - 1.0, av, f);
             a += av;
         }
     }
     f = wave_sum(f);
     a = wave_sum(a);
-    __syncthreads();
+    const int tid = threadIdx.x;
     if ((tid & 63) == 0) { red[tid >> 6] = f; red[BT / 64 + (tid >> 6)] = a; }
     __syncthreads();
     if (tid < 2) {
@@ -482,17 +504,18 @@ __global__ __launch_bounds__(BT) void kb_fix_ranks(const unsigned* key, const un
         part[((size_t)blockIdx.y * GXMAX + blockIdx.x) * 2 + tid] = t;
     }
 }
-// delta of the element at sorted position p, written to its home
-__global__ __launch_bounds__(BT) void kb_delta_scatter(const unsigned* rank, const unsigned* idx, const double* F, double* Dout,
-                                                       const double* fg, unsigned n, const unsigned* segs) {
-    const size_t off = segs[2 * blockIdx.y];
-    const unsigned count = segs[2 * blockIdx.y + 1];
+// delta_j = -((2 rank_j - n - 1) sign g - f n sign) / g^2 at home positions; Dout may be Yin
+__global__ __launch_bounds__(BT) void kb_delta_home(const double* Yin, const unsigned* rank, double* Dout, const double* fg,
+                                                    unsigned n) {
+    const size_t off = (size_t)blockIdx.y * n;
     const double f = fg[2 * blockIdx.y], g = fg[2 * blockIdx.y + 1];
     const double inv_g2 = 1.0 / (g * g);
-    for (unsigned p = blockIdx.x * BT + threadIdx.x; p < count; p += gridDim.x * BT) {
-        const double sg = sign_ref(F[off + p]);
-        const double df = (2.0 * (double)rank[off + p] - (double)n - 1.0) * sg;
-        Dout[idx[off + p]] = -(df * g - f * ((double)n * sg)) * inv_g2;
+    for (unsigned j = blockIdx.x * BT + threadIdx.x; j < n; j += gridDim.x * BT) {
+        const double y = Yin[off + j];
+        const double sg = sign_ref(y);
+        const double coef = (y != 0.0) ? 2.0 * (double)rank[off + j] - (double)n - 1.0 : 0.0;
+        const double df = coef * sg;
+        Dout[off + j] = -(df * g - f * ((double)n * sg)) * inv_g2;
     }
 }
 
@@ -641,6 +664,7 @@ int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, dou
         hipLaunchKernelGGL(kb_scan_counts, dim3(1), dim3(BT), 0, st, counts, Bs * bpe, bpe, Bs, segs + 2 * (size_t)e0, totals + sl);
     }
     WN_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(unsigned), st));
+    const int gx = (int)std::min<size_t>(n / FIX_TILE, GXMAX);
     std::vector<unsigned> nonzero(nslices);
     WN_HIP(ctx, hipMemcpyAsync(nonzero.data(), totals, nslices * sizeof(unsigned), hipMemcpyDeviceToHost, st));
     WN_HIP(ctx, hipStreamSynchronize(st));   // the sorts take their sizes from the host
@@ -652,28 +676,23 @@ int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, dou
         unsigned* keyB = keyA + (size_t)Bs * n;
         hipLaunchKernelGGL(kb_key32_compact, dim3(Bs * bpe), dim3(BT), 0, st, Y + off, cnt + (size_t)e0 * bpe, keyA, idxA + off, lgn, magbits);
         WN_HIP(ctx, rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keyA, keyB, idxA + off, idxB + off, total, 0, 32, st));
-        const unsigned blocks = (unsigned)std::min<size_t>((total + BT - 1) / BT, 65536);
-        hipLaunchKernelGGL(kb_gather_sorted, dim3(blocks), dim3(BT), 0, st, Y + off, keyB, idxB + off, keysB + off, total, flag);
+        // ranks go to the slice of keysB (free: the sorted keys sit in the second half of the slice of keysA)
+        hipLaunchKernelGGL(kb_rank_home, dim3((unsigned)gx * (((unsigned)Bs + 7u) & ~7u)), dim3(BT), 0, st, keyB, idxB + off, Y + off,
+                           (unsigned)n, segs + 2 * (size_t)e0, reinterpret_cast<unsigned*>(keysB + off), flag, gx, Bs);
     }
     unsigned over = 0;
     WN_HIP(ctx, hipMemcpyAsync(&over, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     WN_HIP(ctx, hipStreamSynchronize(st));
     if (over) return gini_big(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, gpart, fg, S_e, sort_tmp, sort_tmp_bytes);
-    const int gx = (int)std::min<size_t>(n / FIX_TILE, GXMAX);
-    // the zeros' errors are zero: in place they already are, elsewhere they are written here
-    if (D && D != Y) WN_HIP(ctx, hipMemsetAsync(D, 0, (size_t)B * n * sizeof(double), st));
     for (int e0 = 0; e0 < B; e0 += slice) {
         const int Bs = std::min(slice, B - e0);
         const size_t off = (size_t)e0 * n;
-        unsigned* keyA = reinterpret_cast<unsigned*>(keysA + off);
-        unsigned* keyB = keyA + (size_t)Bs * n;
-        unsigned* rank = keyA;
-        hipLaunchKernelGGL(kb_fix_ranks, dim3(gx, Bs), dim3(BT), 0, st, keyB, idxB + off, keysB + off, (unsigned)n,
-                           segs + 2 * (size_t)e0, rank, gpart + (size_t)e0 * GXMAX * 2);
+        const unsigned* rk = reinterpret_cast<const unsigned*>(keysB + off);
+        hipLaunchKernelGGL(kb_sums_home, dim3(gx, Bs), dim3(BT), 0, st, Y + off, rk, (unsigned)n, gpart + (size_t)e0 * GXMAX * 2);
         hipLaunchKernelGGL(kb_gini_finish, dim3((Bs + BT - 1) / BT), dim3(BT), 0, st, gpart + (size_t)e0 * GXMAX * 2, Bs, gx,
                            (unsigned)n, fg + 2 * (size_t)e0, S_e ? S_e + e0 : nullptr);
-        if (D) hipLaunchKernelGGL(kb_delta_scatter, grid_for((int)std::min<size_t>(n, 1u << 30), Bs), dim3(BT), 0, st, rank,
-                                  idxB + off, keysB + off, D + off, fg + 2 * (size_t)e0, (unsigned)n, segs + 2 * (size_t)e0);
+        if (D) hipLaunchKernelGGL(kb_delta_home, grid_for((int)std::min<size_t>(n, 1u << 30), Bs), dim3(BT), 0, st, Y + off, rk,
+                                  D + off, fg + 2 * (size_t)e0, (unsigned)n);
     }
     WN_HIP(ctx, hipGetLastError());
     return WN_OK;
