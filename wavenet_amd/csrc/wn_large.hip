@@ -213,24 +213,27 @@ __global__ void kb_grad_finish(const double* partial, int NP, const FilterDev* f
     if (k >= 0 && k < filt->N) grad_e[(size_t)ex * filt->N + k] = filt->vL[kp] * gl + filt->sH[kp] * gh;
 }
 
-// sums[0..N) += sum_e grad_e, sums[N] += sum_e S_e, sums[N+1] += number of non-finite values; example order.
-__global__ void kb_batch_sums(const double* grad_e, const double* S_e, int B, int N, double* sums, int first) {
-    const int t = threadIdx.x;
+// sums[0..N) += sum_e grad_e, sums[N] += sum_e S_e, sums[N+1] += number of non-finite values.  One wave per
+// quantity (grid N + 2): lane l adds examples l, l + 64, ... in order, the lanes are combined by a
+// butterfly -- a fixed order.
+__global__ __launch_bounds__(64) void kb_batch_sums(const double* grad_e, const double* S_e, int B, int N, double* sums, int first) {
+    const int t = blockIdx.x, lane = threadIdx.x;
     if (t > N + 1) return;
-    double s = first ? 0.0 : sums[t];
+    double s = 0;
     if (t < N) {
-        for (int e = 0; e < B; e++) s += grad_e[(size_t)e * N + t];
+        for (int e = lane; e < B; e += 64) s += grad_e[(size_t)e * N + t];
     } else if (t == N) {
-        for (int e = 0; e < B; e++) s += S_e[e];
+        for (int e = lane; e < B; e += 64) s += S_e[e];
     } else {
-        for (int e = 0; e < B; e++) {
+        for (int e = lane; e < B; e += 64) {
             if (!isfinite(S_e[e])) s += 1;
             for (int k = 0; k < N; k++) {
                 if (!isfinite(grad_e[(size_t)e * N + k])) s += 1;
             }
         }
     }
-    sums[t] = s;
+    s = wave_sum(s);
+    if (lane == 0) sums[t] = (first ? 0.0 : sums[t]) + s;
 }
 
 // ---- Gini --------------------------------------------------------------------------------------------
@@ -786,7 +789,7 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
             if ((rc = bwd_pass_big<NP>(ctx, D1, Xc, Prow, other, Pcol, Bc, n, rg, false, pl.partial, nullptr))) return rc;
         }
         hipLaunchKernelGGL(kb_grad_finish, dim3(Bc), dim3(64), 0, st, pl.partial, NP, ctx->dfilt, grad_e);
-        hipLaunchKernelGGL(kb_batch_sums, dim3(1), dim3(64), 0, st, grad_e, S_e, Bc, N, ctx->sums, e0 == 0 ? 1 : 0);
+        hipLaunchKernelGGL(kb_batch_sums, dim3(N + 2), dim3(64), 0, st, grad_e, S_e, Bc, N, ctx->sums, e0 == 0 ? 1 : 0);
         WN_HIP(ctx, hipGetLastError());
     }
     return WN_OK;
