@@ -324,3 +324,20 @@ def test_sparse_cost_grid(ctx, oracle, R, C, N, F_):
         for e in range(B):
             Y = oracle.band_forward_2d(filters[f], X[e])[3]
             assert S[f, e] == pytest.approx(oracle.sparse_term(Y), rel=1e-10)
+
+
+@pytest.mark.parametrize("R,C,N", [(64, 64, 4), (1024, 1, 16)])
+def test_drift_over_updates(R, C, N):
+    """100 updates of batch 8 against the banded restatement: the one-step error with the device put back
+    on the CPU filter before every update (tolerance 1e-9 per step) and the free-running drift after 10
+    and 100 updates (tools/drift_report.py; 1000 updates are in profiles/r01_drift.json)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "drift_report.py")
+    spec = importlib.util.spec_from_file_location("drift_report", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rep = mod.run(R, C, N, 8, 100, [10, 100])
+    assert rep["max_one_step_relative_error"] < 1e-9, rep
+    drift = rep["free_running_relative_drift_after_updates"]
+    assert drift["10"] < 1e-9 and drift["100"] < 1e-8, rep

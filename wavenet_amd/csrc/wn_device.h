@@ -509,12 +509,7 @@ __device__ __forceinline__ double gini_phase(double* bufY, int n, double* red, i
         double sv[K];
 #pragma unroll
         for (int r = 0; r < K; r++) sv[r] = kv[r];
-#ifdef WN_GINI_SKIP_SORT
-        for (int r = 0; r < K; r++) bufY[e0 + r] = sv[r];
-        __syncthreads();
-#else
         sort_full<LGN, Q>(sv, bufY, (unsigned)tid);
-#endif
     }
 
     unsigned lb[K];
@@ -523,11 +518,7 @@ __device__ __forceinline__ double gini_phase(double* bufY, int n, double* red, i
     for (int r = 0; r < K; r++) {
         lb[r] = 0;
         if (e0 + r < (unsigned)n) {
-#ifdef WN_GINI_SKIP_SEARCH
-            lb[r] = e0 + r;
-#else
             lb[r] = lower_bound_sorted<LGN>(bufY, kv[r]);
-#endif
             if (kv[r] != 0.0 && lb[r] + 1 < (1u << LGN) && bufY[lb[r] + 1] == kv[r]) tie = true;
         }
     }

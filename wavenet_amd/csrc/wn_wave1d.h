@@ -10,6 +10,9 @@
 // straight-line code on registers with compile-time indices; the low-pass pyramid of the backward
 // pass simply stays in registers (36 doubles).  LDS holds only the 1024 coefficients for the Gini
 // phase, which is the one of the workgroup-per-example kernels run by a single wave.
+//
+// Build switches for timing experiments (tools/build_variant.sh): W1D_SKIP_GINI, W1D_SKIP_BWD leave a
+// phase out (wrong results), W1D_WAVES sets the waves per SIMD the register budget is compiled for.
 #pragma once
 
 #include "wn_kernels.h"
@@ -44,8 +47,6 @@ __device__ __forceinline__ void w1d_extend(const double (&own)[M], double (&ext)
     for (int i = 0; i < M; i++) ext[HL + i] = own[i];
 #pragma unroll
     for (int t = 0; t < HL; t++) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int d = 1 + t / M, reg = M - 1 - (t % M);
         // distance d is a compile-time value after unrolling; the switch keeps it a template argument
         double v;
