@@ -26,7 +26,7 @@ def filt_for(N, seed=0):
 
 
 @pytest.mark.parametrize("R,C,N", [(128, 64, 4), (64, 128, 2), (8192, 1, 16), (1, 8192, 6), (256, 128, 32), (2, 4096, 8),
-                                   (512, 512, 4)])
+                                   (512, 512, 4), (512, 16, 8), (512, 32, 32)])
 def test_forward_inverse_backprop(ctx, oracle, R, C, N):
     import torch
     B = 2
@@ -80,7 +80,8 @@ def test_sparse_term_and_deriv(ctx, oracle, n):
 
 
 @pytest.mark.parametrize("R,C,N,B", [(128, 64, 4, 5), (8192, 1, 16, 3), (512, 512, 4, 2), (512, 512, 16, 2),
-                                     (1 << 20, 1, 32, 2)])
+                                     (1 << 20, 1, 32, 2), (512, 16, 6, 3), (512, 64, 32, 2), (512, 32, 2, 70),
+                                     (512, 128, 8, 2)])
 def test_train_batch(ctx, oracle, R, C, N, B):
     """Batch sums and per-example values of the full step; 512x512 and 2^20 x 1 are the full sizes of the
     data-parallel configurations."""

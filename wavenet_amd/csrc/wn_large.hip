@@ -15,12 +15,14 @@
 #include <vector>
 
 #include "wn_internal.h"
+#include "wn_lines512.h"
 
 namespace wn {
 namespace {
 
 constexpr int BT = 256;        // threads per workgroup
 constexpr int GXMAX = 64;      // workgroups per example in the reducing kernels
+static_assert(GXMAX == L512_GX, "the column kernels of wn_lines512.h write the same partial-sum slots");
 
 struct Geom {                   // lines of one pass inside an example of n doubles
     int es, ls, lgNL, lgLen;
@@ -775,14 +777,31 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         double* Pcol = PcolOut ? PcolOut + (size_t)e0 * n : pl.Pcol;
         double* YD = Yout ? Yout + (size_t)e0 * n : pl.YD;
         if ((rc = fwd_pass_big<NP>(ctx, Xc, Prow, Y1, Bc, n, rg))) return rc;
-        if ((rc = fwd_pass_big<NP>(ctx, Y1, Pcol, YD, Bc, n, cg))) return rc;
+        // images with 512 rows: one wave per column, cascade in registers (wn_lines512.h); the pyramid of
+        // the column pass is written only for a caller that asked for it -- the backward pass rebuilds it
+        const bool cols512 = (lgR == 9 && lgC > 0 && ctx->wave64);
+        const int C = 1 << lgC;
+        if (cols512) {
+            hipLaunchKernelGGL(kc_fwd_cols512<NP>, dim3(std::min(C, L512_GX), Bc), dim3(64), 0, st, Y1, YD, PcolOut ? Pcol : nullptr,
+                               n, C, ctx->dfilt);
+            WN_HIP(ctx, hipGetLastError());
+        } else if ((rc = fwd_pass_big<NP>(ctx, Y1, Pcol, YD, Bc, n, cg))) {
+            return rc;
+        }
         if (forward_only) continue;
         double* S_e = S ? S + e0 : pl.S_e;
         double* grad_e = grad ? grad + (size_t)e0 * N : pl.grad_e;
         if ((rc = gini_large(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes))) return rc;
         WN_HIP(ctx, hipMemsetAsync(pl.partial, 0, (size_t)Bc * GXMAX * 2 * NP * sizeof(double), st));
         const double* D1 = nullptr;
-        if ((rc = bwd_pass_big<NP>(ctx, YD, Y1, Pcol, pl.A, pl.Bb, Bc, n, cg, lgC > 0, pl.partial, &D1))) return rc;
+        if (cols512) {
+            hipLaunchKernelGGL(kc_bwd_cols512<NP>, dim3(std::min(C, L512_GX), Bc), dim3(64), 0, st, YD, Y1, pl.A, n, C, ctx->dfilt,
+                               pl.partial);
+            WN_HIP(ctx, hipGetLastError());
+            D1 = pl.A;
+        } else if ((rc = bwd_pass_big<NP>(ctx, YD, Y1, Pcol, pl.A, pl.Bb, Bc, n, cg, lgC > 0, pl.partial, &D1))) {
+            return rc;
+        }
         if (lgC > 0) {
             // D1 sits in A or Bb (or is YD itself when the column pass had no level); scratch: the other one and Pcol
             double* other = (D1 == pl.A) ? pl.Bb : pl.A;
