@@ -644,7 +644,11 @@ int gini_big(wn_context* ctx, const double* Y, double* D, int B, size_t n, doubl
 // sorted in slices of at most 2^23 coefficients (32 examples of 512x512, 8 signals of 2^20 samples).
 int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB,
                unsigned* idxA, unsigned* idxB, unsigned* cnt, double* gpart, double* fg, double* S_e, void* sort_tmp,
-               size_t sort_tmp_bytes) {
+               size_t sort_tmp_bytes, int* rank_slice = nullptr) {
+    // rank_slice (with D null): receives the number of examples per slice when the ranks were left in keysB
+    // (slice s at keysB + s * slice * n, as 32-bit ranks at home positions) for a consumer that computes
+    // the errors itself, 0 when this path did not apply and only the sums were computed.
+    if (rank_slice) *rank_slice = 0;
     int lgn = 0;
     while (((size_t)1 << lgn) < n) lgn++;
     const int exbits_max = 26 - lgn;   // slices of 2^26 coefficients
@@ -700,6 +704,7 @@ int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, dou
                                   D + off, fg + 2 * (size_t)e0, (unsigned)n);
     }
     WN_HIP(ctx, hipGetLastError());
+    if (rank_slice) *rank_slice = slice;
     return WN_OK;
 }
 
@@ -791,12 +796,24 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         if (forward_only) continue;
         double* S_e = S ? S + e0 : pl.S_e;
         double* grad_e = grad ? grad + (size_t)e0 * N : pl.grad_e;
-        if ((rc = gini_large(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes))) return rc;
+        // with the column kernels the errors on the coefficients are computed inside the backward kernel from
+        // the ranks; otherwise (or when the short-key ranking did not apply) they replace the coefficients in YD
+        int rank_slice = 0;
+        if (cols512 && (rc = gini_large(ctx, YD, nullptr, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp,
+                                        pl.sort_tmp_bytes, &rank_slice)))
+            return rc;
+        if (!rank_slice &&
+            (rc = gini_large(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes)))
+            return rc;
         WN_HIP(ctx, hipMemsetAsync(pl.partial, 0, (size_t)Bc * GXMAX * 2 * NP * sizeof(double), st));
         const double* D1 = nullptr;
         if (cols512) {
-            hipLaunchKernelGGL(kc_bwd_cols512<NP>, dim3(std::min(C, L512_GX), Bc), dim3(64), 0, st, YD, Y1, pl.A, n, C, ctx->dfilt,
-                               pl.partial);
+            if (rank_slice)
+                hipLaunchKernelGGL((kc_bwd_cols512<NP, true>), dim3(std::min(C, L512_GX), Bc), dim3(64), 0, st, YD, Y1, pl.A, n, C,
+                                   ctx->dfilt, pl.partial, pl.Bb, rank_slice, pl.fg);
+            else
+                hipLaunchKernelGGL((kc_bwd_cols512<NP, false>), dim3(std::min(C, L512_GX), Bc), dim3(64), 0, st, YD, Y1, pl.A, n, C,
+                                   ctx->dfilt, pl.partial, nullptr, 1, nullptr);
             WN_HIP(ctx, hipGetLastError());
             D1 = pl.A;
         } else if ((rc = bwd_pass_big<NP>(ctx, YD, Y1, Pcol, pl.A, pl.Bb, Bc, n, cg, lgC > 0, pl.partial, &D1))) {

@@ -96,13 +96,29 @@ __global__ __launch_bounds__(64, (NP > 16 ? 1 : 2)) void kc_fwd_cols512(const do
     }
 }
 
-// Errors on the coefficients of the columns (coef) and the columns themselves (in) -> errors on the
-// columns (out, may be null: last pass) and the window sums of the filter gradient, added to
-// partial[(example * L512_GX + workgroup) * 2 NP + u] as the level kernels do.
-template <int NP>
+// The error on one coefficient from its value and rank (kb_delta_home of the streamed path, same expression).
+struct L512Gini {
+    double f, g, inv_g2, n;
+    __device__ __forceinline__ double delta(double y, unsigned rank) const {
+        const double sg = sign_ref(y);
+        const double coef = (y != 0.0) ? 2.0 * (double)rank - n - 1.0 : 0.0;
+        const double df = coef * sg;
+        return -(df * g - f * (n * sg)) * inv_g2;
+    }
+};
+
+// Errors on the coefficients of the columns and the columns themselves (in) -> errors on the columns
+// (out, may be null: last pass) and the window sums of the filter gradient, added to
+// partial[(example * L512_GX + workgroup) * 2 NP + u] as the level kernels do.  The errors on the
+// coefficients are read from coef, or with FROM_RANKS computed on the way in from the coefficients
+// (coef), their ranks and the example's sums fg = {f, g}: the array of errors is then never written.
+// ranks: per slice of `slice` examples an array of slice * n ranks at ranks + slice_first_example * n
+// DOUBLES (the streamed path's layout).
+template <int NP, bool FROM_RANKS>
 __global__ __launch_bounds__(64, (NP > 16 ? 1 : 2)) void kc_bwd_cols512(const double* __restrict__ coef, const double* __restrict__ in,
                                                                         double* __restrict__ out, size_t xs, int ncols,
-                                                                        const FilterDev* filt, double* partial) {
+                                                                        const FilterDev* filt, double* partial,
+                                                                        const double* ranks, int slice, const double* fg) {
     const int lane = threadIdx.x;
     double a[NP], b[NP];
     l512_load_taps<NP>(filt, a, b);
@@ -110,13 +126,42 @@ __global__ __launch_bounds__(64, (NP > 16 ? 1 : 2)) void kc_bwd_cols512(const do
 #pragma unroll
     for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
     const size_t off = (size_t)blockIdx.y * xs;
+    L512Gini gini{0, 0, 0, (double)xs};
+    const unsigned* rk = nullptr;
+    if constexpr (FROM_RANKS) {
+        const int e = blockIdx.y, e0 = (e / slice) * slice;
+        rk = reinterpret_cast<const unsigned*>(ranks + (size_t)e0 * xs) + (size_t)(e - e0) * xs;
+        gini.f = fg[2 * e];
+        gini.g = fg[2 * e + 1];
+        gini.inv_g2 = 1.0 / (gini.g * gini.g);
+    }
     for (int c = blockIdx.x; c < ncols; c += gridDim.x) {
         const size_t lo = off + (size_t)c * 512;
         Lines512Pyramid<NP> p;
         l512_load_line(in + lo, p.x, lane);
         l512_forward<NP>(p, a, b, lane, nullptr, nullptr);
         const double* dc = coef + lo;
-        const double dsmall = dc[lane];                       // errors on coefficients 0..63, one per lane
+        const unsigned* rc = rk + (size_t)c * 512;
+        // errors on the coefficients, in the lane layout of the cascade
+        double dsmall, h1[1], h2[2], h4[4];
+        {
+            dsmall = dc[lane];
+            h1[0] = dc[64 + lane];
+            const double2 t2 = *reinterpret_cast<const double2*>(dc + 128 + 2 * lane);
+            h2[0] = t2.x; h2[1] = t2.y;
+            const double2* t = reinterpret_cast<const double2*>(dc + 256 + 4 * lane);
+            const double2 t0 = t[0], t1 = t[1];
+            h4[0] = t0.x; h4[1] = t0.y; h4[2] = t1.x; h4[3] = t1.y;
+        }
+        if constexpr (FROM_RANKS) {
+            dsmall = gini.delta(dsmall, rc[lane]);
+            h1[0] = gini.delta(h1[0], rc[64 + lane]);
+            const uint2 r2 = *reinterpret_cast<const uint2*>(rc + 128 + 2 * lane);
+            h2[0] = gini.delta(h2[0], r2.x); h2[1] = gini.delta(h2[1], r2.y);
+            const uint4 r4 = *reinterpret_cast<const uint4*>(rc + 256 + 4 * lane);
+            h4[0] = gini.delta(h4[0], r4.x); h4[1] = gini.delta(h4[1], r4.y);
+            h4[2] = gini.delta(h4[2], r4.z); h4[3] = gini.delta(h4[3], r4.w);
+        }
         double d = w1d_lane(dsmall, 0);                       // lo_0
         d = w1d_bwd_small<NP, 0>(d, w1d_lane(dsmall, 1), p.los[1], a, b, gL, gH, lane);
         d = w1d_bwd_small<NP, 1>(d, w1d_lane(dsmall, 2 + (lane & 1)), p.los[2], a, b, gL, gH, lane);
@@ -124,18 +169,9 @@ __global__ __launch_bounds__(64, (NP > 16 ? 1 : 2)) void kc_bwd_cols512(const do
         d = w1d_bwd_small<NP, 3>(d, w1d_lane(dsmall, 8 + (lane & 7)), p.los[4], a, b, gL, gH, lane);
         d = w1d_bwd_small<NP, 4>(d, w1d_lane(dsmall, 16 + (lane & 15)), p.los[5], a, b, gL, gH, lane);
         d = w1d_bwd_small<NP, 5>(d, w1d_lane(dsmall, 32 + (lane & 31)), p.lo6[0], a, b, gL, gH, lane);
-        double d1[1] = {d}, h1[1] = {dc[64 + lane]}, d2[2], h2[2], d4[4], h4[4], d8[8];
+        double d1[1] = {d}, d2[2], d4[4], d8[8];
         w1d_bwd_block<NP, 1, true>(d1, h1, p.lo7, d2, a, b, gL, gH, lane);
-        {
-            const double2 t = *reinterpret_cast<const double2*>(dc + 128 + 2 * lane);
-            h2[0] = t.x; h2[1] = t.y;
-        }
         w1d_bwd_block<NP, 2, true>(d2, h2, p.lo8, d4, a, b, gL, gH, lane);
-        {
-            const double2* t = reinterpret_cast<const double2*>(dc + 256 + 4 * lane);
-            const double2 t0 = t[0], t1 = t[1];
-            h4[0] = t0.x; h4[1] = t0.y; h4[2] = t1.x; h4[3] = t1.y;
-        }
         if (out) {
             w1d_bwd_block<NP, 4, true>(d4, h4, p.x, d8, a, b, gL, gH, lane);
             double2* o = reinterpret_cast<double2*>(out + lo + 8 * lane);
