@@ -409,6 +409,7 @@ __global__ __launch_bounds__(BT) void kb_key32_compact(const double* Y, const un
     }
 }
 constexpr int FIX_TILE = 2048, FIX_HALO = 32;   // sorted positions staged in LDS per step, and on either side
+constexpr int RANK_TILE = 1024, RANK_GX = 256;  // kb_rank_home: smaller steps, one example per XCD at a time
 
 // ---- ranks written home -----------------------------------------------------------------------------------
 // The sorted order is only read, never materialised as values: kb_rank_home walks the sorted (key, position)
@@ -423,8 +424,8 @@ constexpr int FIX_TILE = 2048, FIX_HALO = 32;   // sorted positions staged in LD
 // whose L2 then collects the example's scattered ranks (1 MB at 512x512) into whole lines.
 __global__ __launch_bounds__(BT) void kb_rank_home(const unsigned* key, const unsigned* idx, const double* Y, unsigned n,
                                                    const unsigned* segs, unsigned* rank, unsigned* flag, int gx, int B) {
-    __shared__ double la[FIX_TILE + 2 * FIX_HALO];
-    __shared__ unsigned lk[FIX_TILE + 2 * FIX_HALO], li[FIX_TILE + 2 * FIX_HALO];
+    __shared__ double la[RANK_TILE + 2 * FIX_HALO];
+    __shared__ unsigned lk[RANK_TILE + 2 * FIX_HALO], li[RANK_TILE + 2 * FIX_HALO];
     const int slot = blockIdx.x >> 3;
     const int ex = (slot / gx) * 8 + (blockIdx.x & 7), bx = slot % gx;
     if (ex >= B) return;
@@ -432,8 +433,8 @@ __global__ __launch_bounds__(BT) void kb_rank_home(const unsigned* key, const un
     const unsigned zeros = n - segs[2 * ex + 1];
     const int tid = threadIdx.x;
     bool over = false;
-    for (size_t t0 = exstart + (size_t)bx * FIX_TILE; t0 < exend; t0 += (size_t)gx * FIX_TILE) {
-        const size_t tile = (exend - t0 < (size_t)FIX_TILE) ? exend - t0 : (size_t)FIX_TILE;
+    for (size_t t0 = exstart + (size_t)bx * RANK_TILE; t0 < exend; t0 += (size_t)gx * RANK_TILE) {
+        const size_t tile = (exend - t0 < (size_t)RANK_TILE) ? exend - t0 : (size_t)RANK_TILE;
         const size_t lo = (t0 >= exstart + FIX_HALO) ? t0 - FIX_HALO : exstart;
         const size_t hi = (t0 + tile + FIX_HALO <= exend) ? t0 + tile + FIX_HALO : exend;
         const int cnt = (int)(hi - lo);
@@ -686,8 +687,9 @@ int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, dou
         hipLaunchKernelGGL(kb_key32_compact, dim3(Bs * bpe), dim3(BT), 0, st, Y + off, cnt + (size_t)e0 * bpe, keyA, idxA + off, lgn, magbits);
         WN_HIP(ctx, rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keyA, keyB, idxA + off, idxB + off, total, 0, 32, st));
         // ranks go to the slice of keysB (free: the sorted keys sit in the second half of the slice of keysA)
-        hipLaunchKernelGGL(kb_rank_home, dim3((unsigned)gx * (((unsigned)Bs + 7u) & ~7u)), dim3(BT), 0, st, keyB, idxB + off, Y + off,
-                           (unsigned)n, segs + 2 * (size_t)e0, reinterpret_cast<unsigned*>(keysB + off), flag, gx, Bs);
+        const int rgx = (int)std::min<size_t>(n / RANK_TILE, RANK_GX);
+        hipLaunchKernelGGL(kb_rank_home, dim3((unsigned)rgx * (((unsigned)Bs + 7u) & ~7u)), dim3(BT), 0, st, keyB, idxB + off, Y + off,
+                           (unsigned)n, segs + 2 * (size_t)e0, reinterpret_cast<unsigned*>(keysB + off), flag, rgx, Bs);
     }
     unsigned over = 0;
     WN_HIP(ctx, hipMemcpyAsync(&over, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
