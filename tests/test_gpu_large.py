@@ -81,7 +81,8 @@ def test_sparse_term_and_deriv(ctx, oracle, n):
 
 @pytest.mark.parametrize("R,C,N,B", [(128, 64, 4, 5), (8192, 1, 16, 3), (512, 512, 4, 2), (512, 512, 16, 2),
                                      (1 << 20, 1, 32, 2), (512, 16, 6, 3), (512, 64, 32, 2), (512, 32, 2, 70),
-                                     (512, 128, 8, 2)])
+                                     (512, 128, 8, 2), (16, 512, 4, 3), (64, 512, 16, 2), (128, 512, 32, 2),
+                                     (1024, 512, 2, 2), (32, 512, 6, 40)])
 def test_train_batch(ctx, oracle, R, C, N, B):
     """Batch sums and per-example values of the full step; 512x512 and 2^20 x 1 are the full sizes of the
     data-parallel configurations."""
@@ -231,3 +232,21 @@ def test_sparse_term_magnitudes_outside_the_key_range(ctx, oracle, n):
     for e in range(B):
         assert S[e] == pytest.approx(oracle.sparse_term(Y[e]), rel=1e-11)
         assert relerr(D[e], oracle.sparse_term_deriv(Y[e])) < 1e-10
+
+
+@pytest.mark.parametrize("R,C,N", [(512, 512, 4), (64, 512, 8), (512, 32, 16)])
+def test_forward_coefficients_only(ctx, R, C, N):
+    """wn_forward asked for the coefficients alone takes the one-wave-per-line kernels for lines of 512
+    samples; asked for the activations as well it takes the level kernels.  Same coefficients."""
+    import torch
+    from wavenet_amd import generators as G
+    B = 3
+    X = G.calorimeter(B, R, C, seed=5)
+    ctx.set_filter(filt_for(N, 3))
+    n = R * C
+    dX = to_dev(X)
+    dY, dY2, dPr, dY1, dPc = (dev_empty(B * n) for _ in range(5))
+    ctx.forward(dX, B, R, C, dY)
+    ctx.forward(dX, B, R, C, dY2, dPr, dY1, dPc)
+    torch.cuda.synchronize()
+    assert torch.allclose(dY, dY2, rtol=1e-13, atol=1e-15)

@@ -783,7 +783,19 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         double* Y1 = Y1Out ? Y1Out + (size_t)e0 * n : pl.Y1;
         double* Pcol = PcolOut ? PcolOut + (size_t)e0 * n : pl.Pcol;
         double* YD = Yout ? Yout + (size_t)e0 * n : pl.YD;
-        if ((rc = fwd_pass_big<NP>(ctx, Xc, Prow, Y1, Bc, n, rg))) return rc;
+        // images with 512 columns (and 16 .. 1024 rows): 16 rows per workgroup through an LDS tile, one wave
+        // per row (wn_lines512.h); no row pyramid is written unless the caller asked for it
+        const bool rows512 = (lgC == 9 && lgR >= 4 && lgR <= 10 && ctx->wave64 && !ProwOut);
+        if (rows512) {
+            // LDS beyond the default limit
+            WN_HIP(ctx, hipFuncSetAttribute((const void*)kr_fwd_rows512<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L512_TILE_BYTES));
+            WN_HIP(ctx, hipFuncSetAttribute((const void*)kr_grad_rows512<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L512_TILE_BYTES));
+            hipLaunchKernelGGL(kr_fwd_rows512<NP>, dim3((1 << lgR) / L512_ROWS, Bc), dim3(256), L512_TILE_BYTES, st, Xc, Y1, n, 1 << lgR,
+                               ctx->dfilt);
+            WN_HIP(ctx, hipGetLastError());
+        } else if ((rc = fwd_pass_big<NP>(ctx, Xc, Prow, Y1, Bc, n, rg))) {
+            return rc;
+        }
         // images with 512 rows: one wave per column, cascade in registers (wn_lines512.h); the pyramid of
         // the column pass is written only for a caller that asked for it -- the backward pass rebuilds it
         const bool cols512 = (lgR == 9 && lgC > 0 && ctx->wave64);
@@ -824,7 +836,13 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         if (lgC > 0) {
             // D1 sits in A or Bb (or is YD itself when the column pass had no level); scratch: the other one and Pcol
             double* other = (D1 == pl.A) ? pl.Bb : pl.A;
-            if ((rc = bwd_pass_big<NP>(ctx, D1, Xc, Prow, other, Pcol, Bc, n, rg, false, pl.partial, nullptr))) return rc;
+            if (rows512) {
+                hipLaunchKernelGGL(kr_grad_rows512<NP>, dim3((1 << lgR) / L512_ROWS, Bc), dim3(256), L512_TILE_BYTES, st, D1, Xc, n,
+                                   1 << lgR, ctx->dfilt, pl.partial);
+                WN_HIP(ctx, hipGetLastError());
+            } else if ((rc = bwd_pass_big<NP>(ctx, D1, Xc, Prow, other, Pcol, Bc, n, rg, false, pl.partial, nullptr))) {
+                return rc;
+            }
         }
         hipLaunchKernelGGL(kb_grad_finish, dim3(Bc), dim3(64), 0, st, pl.partial, NP, ctx->dfilt, grad_e);
         hipLaunchKernelGGL(kb_batch_sums, dim3(N + 2), dim3(64), 0, st, grad_e, S_e, Bc, N, ctx->sums, e0 == 0 ? 1 : 0);
