@@ -82,7 +82,9 @@ def test_sparse_term_and_deriv(ctx, oracle, n):
 @pytest.mark.parametrize("R,C,N,B", [(128, 64, 4, 5), (8192, 1, 16, 3), (512, 512, 4, 2), (512, 512, 16, 2),
                                      (1 << 20, 1, 32, 2), (512, 16, 6, 3), (512, 64, 32, 2), (512, 32, 2, 70),
                                      (512, 128, 8, 2), (16, 512, 4, 3), (64, 512, 16, 2), (128, 512, 32, 2),
-                                     (1024, 512, 2, 2), (32, 512, 6, 40)])
+                                     (1024, 512, 2, 2), (32, 512, 6, 40), (128, 128, 4, 3), (256, 256, 8, 2),
+                                     (1024, 128, 2, 2), (128, 1024, 16, 2), (256, 64, 32, 2), (1024, 1024, 4, 1),
+                                     (2048, 256, 4, 2), (8, 1024, 6, 5)])
 def test_train_batch(ctx, oracle, R, C, N, B):
     """Batch sums and per-example values of the full step; 512x512 and 2^20 x 1 are the full sizes of the
     data-parallel configurations."""
@@ -234,9 +236,9 @@ def test_sparse_term_magnitudes_outside_the_key_range(ctx, oracle, n):
         assert relerr(D[e], oracle.sparse_term_deriv(Y[e])) < 1e-10
 
 
-@pytest.mark.parametrize("R,C,N", [(512, 512, 4), (64, 512, 8), (512, 32, 16)])
+@pytest.mark.parametrize("R,C,N", [(512, 512, 4), (64, 512, 8), (512, 32, 16), (256, 256, 4), (128, 1024, 8), (1024, 128, 32)])
 def test_forward_coefficients_only(ctx, R, C, N):
-    """wn_forward asked for the coefficients alone takes the one-wave-per-line kernels for lines of 512
+    """wn_forward asked for the coefficients alone takes the one-wave-per-line kernels for lines of 128 ... 1024
     samples; asked for the activations as well it takes the level kernels.  Same coefficients."""
     import torch
     from wavenet_amd import generators as G

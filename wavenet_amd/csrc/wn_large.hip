@@ -15,14 +15,36 @@
 #include <vector>
 
 #include "wn_internal.h"
-#include "wn_lines512.h"
+
+extern "C" const void* wn_kernel_lines_np2(int kind, int M);
+extern "C" const void* wn_kernel_lines_np4(int kind, int M);
+extern "C" const void* wn_kernel_lines_np8(int kind, int M);
+extern "C" const void* wn_kernel_lines_np16(int kind, int M);
+extern "C" const void* wn_kernel_lines_np32(int kind, int M);
 
 namespace wn {
 namespace {
 
+// One-wave-per-line kernels (wn_lines.h, compiled per tap count in wn_lines_np.hip).
+enum { LN_FWD_COLS = 0, LN_BWD_COLS = 1, LN_BWD_COLS_RANKS = 2, LN_FWD_ROWS = 3, LN_GRAD_ROWS = 4 };
+const void* line_kernel(int np, int kind, int M) {
+    switch (np) {
+        case 2: return wn_kernel_lines_np2(kind, M);
+        case 4: return wn_kernel_lines_np4(kind, M);
+        case 8: return wn_kernel_lines_np8(kind, M);
+        case 16: return wn_kernel_lines_np16(kind, M);
+        case 32: return wn_kernel_lines_np32(kind, M);
+    }
+    return nullptr;
+}
+// LDS tile of the row kernels: 16 rows (8 for lines of 1024) of 64 (M + 1) + 2 (4) doubles (LineTile in wn_lines.h)
+int line_tile_rows(int M) { return M == 16 ? 8 : 16; }
+size_t line_tile_bytes(int M) { return (size_t)line_tile_rows(M) * (64 * (M + 1) + (M == 16 ? 4 : 2)) * sizeof(double); }
+
 constexpr int BT = 256;        // threads per workgroup
 constexpr int GXMAX = 64;      // workgroups per example in the reducing kernels
-static_assert(GXMAX == L512_GX, "the column kernels of wn_lines512.h write the same partial-sum slots");
+constexpr int LN_GX = 64;      // workgroups per example of the one-wave-per-line kernels (wn_lines.h)
+static_assert(GXMAX == LN_GX, "the line kernels of wn_lines.h write the same partial-sum slots");
 
 struct Geom {                   // lines of one pass inside an example of n doubles
     int es, ls, lgNL, lgLen;
@@ -783,27 +805,34 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         double* Y1 = Y1Out ? Y1Out + (size_t)e0 * n : pl.Y1;
         double* Pcol = PcolOut ? PcolOut + (size_t)e0 * n : pl.Pcol;
         double* YD = Yout ? Yout + (size_t)e0 * n : pl.YD;
-        // images with 512 columns (and 16 .. 1024 rows): 16 rows per workgroup through an LDS tile, one wave
-        // per row (wn_lines512.h); no row pyramid is written unless the caller asked for it
-        const bool rows512 = (lgC == 9 && lgR >= 4 && lgR <= 10 && ctx->wave64 && !ProwOut);
-        if (rows512) {
+        // Lines of 128 .. 1024 samples go through the one-wave-per-line kernels (wn_lines.h): rows in tiles of
+        // 16 (8) adjacent rows through LDS, columns directly.  No pyramid is written unless the caller asked
+        // for it -- the backward kernels rebuild it in registers.
+        const int R = 1 << lgR, C = 1 << lgC;
+        const int Mrow = C / 64, Mcol = R / 64;     // samples per lane
+        const bool rowLines = (lgC >= 7 && lgC <= 10 && R >= line_tile_rows(Mrow) && ctx->wave64 && !ProwOut);
+        const bool colLines = (lgR >= 7 && lgR <= 10 && lgC > 0 && ctx->wave64);
+        const double* Yc = YD;
+        double* pcolArg = PcolOut ? Pcol : nullptr;
+        size_t xs = n;
+        int ncols = C, nrows = R;
+        const FilterDev* dfilt = ctx->dfilt;
+        double* partial = pl.partial;
+        if (rowLines) {
+            const void* fwd = line_kernel(NP, LN_FWD_ROWS, Mrow);
+            const void* grd = line_kernel(NP, LN_GRAD_ROWS, Mrow);
             // LDS beyond the default limit
-            WN_HIP(ctx, hipFuncSetAttribute((const void*)kr_fwd_rows512<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L512_TILE_BYTES));
-            WN_HIP(ctx, hipFuncSetAttribute((const void*)kr_grad_rows512<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L512_TILE_BYTES));
-            hipLaunchKernelGGL(kr_fwd_rows512<NP>, dim3((1 << lgR) / L512_ROWS, Bc), dim3(256), L512_TILE_BYTES, st, Xc, Y1, n, 1 << lgR,
-                               ctx->dfilt);
-            WN_HIP(ctx, hipGetLastError());
+            WN_HIP(ctx, hipFuncSetAttribute(fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_tile_bytes(Mrow)));
+            WN_HIP(ctx, hipFuncSetAttribute(grd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_tile_bytes(Mrow)));
+            void* args[] = {(void*)&Xc, (void*)&Y1, (void*)&xs, (void*)&nrows, (void*)&dfilt};
+            WN_HIP(ctx, hipLaunchKernel(fwd, dim3(std::min(R / line_tile_rows(Mrow), LN_GX), Bc), dim3(256), args, line_tile_bytes(Mrow), st));
         } else if ((rc = fwd_pass_big<NP>(ctx, Xc, Prow, Y1, Bc, n, rg))) {
             return rc;
         }
-        // images with 512 rows: one wave per column, cascade in registers (wn_lines512.h); the pyramid of
-        // the column pass is written only for a caller that asked for it -- the backward pass rebuilds it
-        const bool cols512 = (lgR == 9 && lgC > 0 && ctx->wave64);
-        const int C = 1 << lgC;
-        if (cols512) {
-            hipLaunchKernelGGL(kc_fwd_cols512<NP>, dim3(std::min(C, L512_GX), Bc), dim3(64), 0, st, Y1, YD, PcolOut ? Pcol : nullptr,
-                               n, C, ctx->dfilt);
-            WN_HIP(ctx, hipGetLastError());
+        if (colLines) {
+            const double* y1c = Y1;
+            void* args[] = {(void*)&y1c, (void*)&YD, (void*)&pcolArg, (void*)&xs, (void*)&ncols, (void*)&dfilt};
+            WN_HIP(ctx, hipLaunchKernel(line_kernel(NP, LN_FWD_COLS, Mcol), dim3(std::min(C, LN_GX), Bc), dim3(64), args, 0, st));
         } else if ((rc = fwd_pass_big<NP>(ctx, Y1, Pcol, YD, Bc, n, cg))) {
             return rc;
         }
@@ -813,22 +842,24 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         // with the column kernels the errors on the coefficients are computed inside the backward kernel from
         // the ranks; otherwise (or when the short-key ranking did not apply) they replace the coefficients in YD
         int rank_slice = 0;
-        if (cols512 && (rc = gini_large(ctx, YD, nullptr, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp,
-                                        pl.sort_tmp_bytes, &rank_slice)))
+        if (colLines && (rc = gini_large(ctx, YD, nullptr, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp,
+                                         pl.sort_tmp_bytes, &rank_slice)))
             return rc;
         if (!rank_slice &&
             (rc = gini_large(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes)))
             return rc;
         WN_HIP(ctx, hipMemsetAsync(pl.partial, 0, (size_t)Bc * GXMAX * 2 * NP * sizeof(double), st));
         const double* D1 = nullptr;
-        if (cols512) {
-            if (rank_slice)
-                hipLaunchKernelGGL((kc_bwd_cols512<NP, true>), dim3(std::min(C, L512_GX), Bc), dim3(64), 0, st, YD, Y1, pl.A, n, C,
-                                   ctx->dfilt, pl.partial, pl.Bb, rank_slice, pl.fg);
-            else
-                hipLaunchKernelGGL((kc_bwd_cols512<NP, false>), dim3(std::min(C, L512_GX), Bc), dim3(64), 0, st, YD, Y1, pl.A, n, C,
-                                   ctx->dfilt, pl.partial, nullptr, 1, nullptr);
-            WN_HIP(ctx, hipGetLastError());
+        if (colLines) {
+            const double* y1c = Y1;
+            double* out = pl.A;
+            const double* ranks = rank_slice ? pl.Bb : nullptr;
+            const double* fg = rank_slice ? pl.fg : nullptr;
+            int slice = rank_slice ? rank_slice : 1;
+            void* args[] = {(void*)&Yc, (void*)&y1c, (void*)&out, (void*)&xs, (void*)&ncols, (void*)&dfilt, (void*)&partial,
+                            (void*)&ranks, (void*)&slice, (void*)&fg};
+            WN_HIP(ctx, hipLaunchKernel(line_kernel(NP, rank_slice ? LN_BWD_COLS_RANKS : LN_BWD_COLS, Mcol), dim3(std::min(C, LN_GX), Bc),
+                                        dim3(64), args, 0, st));
             D1 = pl.A;
         } else if ((rc = bwd_pass_big<NP>(ctx, YD, Y1, Pcol, pl.A, pl.Bb, Bc, n, cg, lgC > 0, pl.partial, &D1))) {
             return rc;
@@ -836,10 +867,10 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         if (lgC > 0) {
             // D1 sits in A or Bb (or is YD itself when the column pass had no level); scratch: the other one and Pcol
             double* other = (D1 == pl.A) ? pl.Bb : pl.A;
-            if (rows512) {
-                hipLaunchKernelGGL(kr_grad_rows512<NP>, dim3((1 << lgR) / L512_ROWS, Bc), dim3(256), L512_TILE_BYTES, st, D1, Xc, n,
-                                   1 << lgR, ctx->dfilt, pl.partial);
-                WN_HIP(ctx, hipGetLastError());
+            if (rowLines) {
+                void* args[] = {(void*)&D1, (void*)&Xc, (void*)&xs, (void*)&nrows, (void*)&dfilt, (void*)&partial};
+                WN_HIP(ctx, hipLaunchKernel(line_kernel(NP, LN_GRAD_ROWS, Mrow), dim3(std::min(R / line_tile_rows(Mrow), LN_GX), Bc),
+                                            dim3(256), args, line_tile_bytes(Mrow), st));
             } else if ((rc = bwd_pass_big<NP>(ctx, D1, Xc, Prow, other, Pcol, Bc, n, rg, false, pl.partial, nullptr))) {
                 return rc;
             }

@@ -1,0 +1,384 @@
+// Passes of the streamed path over lines of 128, 256, 512 or 1024 samples: ONE WAVE runs the full-depth
+// cascade of one line in registers (M = 2, 4, 8 or 16 samples per lane), with the blocked / replicated
+// level shapes and the cross-lane halos of wn_wave1d.h.  A line is read once and its coefficients written
+// once (forward), or the errors and the line read once and the errors on the line written once (backward,
+// which rebuilds the low-pass pyramid in registers instead of reading a stored one) -- against one read
+// and one write per LEVEL in the level-by-level kernels.
+//
+// Columns are contiguous (kc_*).  Rows are strided by the number of rows: a workgroup moves 16 (8 for
+// lines of 1024) adjacent rows through an LDS tile, 128 (64) contiguous bytes per column on the global
+// side, one padded row per wave on the LDS side (kr_*).
+//
+// Reference stages: forward_ over the row and column lines (src/Wavenet.cxx:582-606), backpropagate_
+// over them (src/Wavenet.cxx:680-702).
+#pragma once
+
+#include "wn_wave1d.h"
+
+namespace wn {
+
+constexpr int LN_GX = 64;   // workgroups per example; equals GXMAX of the streamed path's partial sums
+
+// One line's values in the lane layout of the cascade: v[0] = index lane (the 64 values of the levels
+// below 64; index 0 is lo_0 for coefficients, 0 for the pyramid), and for c = 1, 2, ..., M/2:
+// v[c + m] = index 64 c + c lane + m, m < c (the level with c values per lane).
+template <int M>
+struct LineLane {
+    double v[M];
+};
+// x: the line, M samples per lane; lo: its low-pass pyramid in the layout of LineLane (lo[0] unused);
+// los[i]: level i < 6 at index lane mod 2^i.
+template <int M>
+struct LinePyramid {
+    double x[M], lo[M], los[6];
+};
+
+template <int NP, int M, int Cc>   // the level with Cc outputs per lane, then the ones below it
+__device__ __forceinline__ void ln_fwd_blocked(LinePyramid<M>& p, LineLane<M>& y, const double (&a)[NP], const double (&b)[NP],
+                                               int lane) {
+    if constexpr (2 * Cc == M) w1d_fwd_block<NP, 2 * Cc>(p.x, &p.lo[Cc], &y.v[Cc], a, b, lane);
+    else w1d_fwd_block<NP, 2 * Cc>(&p.lo[2 * Cc], &p.lo[Cc], &y.v[Cc], a, b, lane);
+    if constexpr (Cc > 1) ln_fwd_blocked<NP, M, Cc / 2>(p, y, a, b, lane);
+}
+
+// The cascade of one line: p.x in, pyramid left in p, coefficients in y; small_lo: the pyramid's value at
+// index lane (layout of the level kernels: level i at [2^i, 2^(i+1)), Y[0] = lo_0, P[0] = 0).
+template <int NP, int M>
+__device__ __forceinline__ void ln_forward(LinePyramid<M>& p, const double (&a)[NP], const double (&b)[NP], int lane,
+                                           LineLane<M>& y, double& small_lo_out) {
+    ln_fwd_blocked<NP, M, M / 2>(p, y, a, b, lane);
+    const double lo6 = p.lo[1];
+    // levels below 64 values, replicated: lane 2^i + k holds low-pass and high-pass value k of level i
+    double his, small_hi = 0, small_lo = 0;
+    w1d_fwd_small<NP, 5>(lo6, p.los[5], his, a, b, lane);
+    if (lane >= 32) { small_hi = his; small_lo = p.los[5]; }
+    w1d_fwd_small<NP, 4>(p.los[5], p.los[4], his, a, b, lane);
+    if (lane >= 16 && lane < 32) { small_hi = his; small_lo = p.los[4]; }
+    w1d_fwd_small<NP, 3>(p.los[4], p.los[3], his, a, b, lane);
+    if (lane >= 8 && lane < 16) { small_hi = his; small_lo = p.los[3]; }
+    w1d_fwd_small<NP, 2>(p.los[3], p.los[2], his, a, b, lane);
+    if (lane >= 4 && lane < 8) { small_hi = his; small_lo = p.los[2]; }
+    w1d_fwd_small<NP, 1>(p.los[2], p.los[1], his, a, b, lane);
+    if (lane >= 2 && lane < 4) { small_hi = his; small_lo = p.los[1]; }
+    w1d_fwd_small<NP, 0>(p.los[1], p.los[0], his, a, b, lane);
+    if (lane == 1) { small_hi = his; small_lo = p.los[0]; }
+    if (lane == 0) { small_hi = p.los[0]; small_lo = 0; }   // Y[0] = lo_0, P[0] = 0
+    y.v[0] = small_hi;
+    small_lo_out = small_lo;
+}
+
+template <int NP, int M, int Cr, bool PROP>   // the level with Cr errors per lane, then the ones above it
+__device__ __forceinline__ void ln_bwd_blocked(const LinePyramid<M>& p, const LineLane<M>& dy, double* dbuf, double* dtop,
+                                               const double (&a)[NP], const double (&b)[NP], double (&gL)[NP], double (&gH)[NP],
+                                               int lane) {
+    if constexpr (2 * Cr == M) {
+        w1d_bwd_block<NP, Cr, PROP>(&dbuf[Cr], &dy.v[Cr], p.x, dtop, a, b, gL, gH, lane);
+    } else {
+        w1d_bwd_block<NP, Cr, true>(&dbuf[Cr], &dy.v[Cr], &p.lo[2 * Cr], &dbuf[2 * Cr], a, b, gL, gH, lane);
+        ln_bwd_blocked<NP, M, 2 * Cr, PROP>(p, dy, dbuf, dtop, a, b, gL, gH, lane);
+    }
+}
+
+// Backward over one line: errors on its coefficients (lane layout) and its pyramid -> window sums of the
+// filter gradient; with PROP the errors on the line itself, dtop[M] per lane.
+template <int NP, int M, bool PROP>
+__device__ __forceinline__ void ln_backward(const LinePyramid<M>& p, const LineLane<M>& dy, double* dtop, const double (&a)[NP],
+                                            const double (&b)[NP], double (&gL)[NP], double (&gH)[NP], int lane) {
+    const double dsmall = dy.v[0];
+    double d = w1d_lane(dsmall, 0);                       // lo_0
+    d = w1d_bwd_small<NP, 0>(d, w1d_lane(dsmall, 1), p.los[1], a, b, gL, gH, lane);
+    d = w1d_bwd_small<NP, 1>(d, w1d_lane(dsmall, 2 + (lane & 1)), p.los[2], a, b, gL, gH, lane);
+    d = w1d_bwd_small<NP, 2>(d, w1d_lane(dsmall, 4 + (lane & 3)), p.los[3], a, b, gL, gH, lane);
+    d = w1d_bwd_small<NP, 3>(d, w1d_lane(dsmall, 8 + (lane & 7)), p.los[4], a, b, gL, gH, lane);
+    d = w1d_bwd_small<NP, 4>(d, w1d_lane(dsmall, 16 + (lane & 15)), p.los[5], a, b, gL, gH, lane);
+    d = w1d_bwd_small<NP, 5>(d, w1d_lane(dsmall, 32 + (lane & 31)), p.lo[1], a, b, gL, gH, lane);
+    double dbuf[M];      // dbuf[c + m]: errors on the low-pass level with c values per lane
+    dbuf[1] = d;
+    ln_bwd_blocked<NP, M, 1, PROP>(p, dy, dbuf, dtop, a, b, gL, gH, lane);
+}
+
+// contiguous line in memory <-> lane layout / samples
+template <int M>
+__device__ __forceinline__ void ln_store(double* Y, const double* v, double small, int lane) {
+    Y[lane] = small;
+    Y[64 + lane] = v[1];
+#pragma unroll
+    for (int c = 2; c < M; c *= 2) {
+        double2* t = reinterpret_cast<double2*>(Y + 64 * c + c * lane);
+#pragma unroll
+        for (int m = 0; m < c; m += 2) t[m / 2] = make_double2(v[c + m], v[c + m + 1]);
+    }
+}
+template <int M>
+__device__ __forceinline__ void ln_load(const double* Y, LineLane<M>& d, int lane) {
+    d.v[0] = Y[lane];
+    d.v[1] = Y[64 + lane];
+#pragma unroll
+    for (int c = 2; c < M; c *= 2) {
+        const double2* t = reinterpret_cast<const double2*>(Y + 64 * c + c * lane);
+#pragma unroll
+        for (int m = 0; m < c; m += 2) { const double2 u = t[m / 2]; d.v[c + m] = u.x; d.v[c + m + 1] = u.y; }
+    }
+}
+template <int M>
+__device__ __forceinline__ void ln_load_samples(const double* src, double* x, int lane) {
+    const double2* s = reinterpret_cast<const double2*>(src + M * lane);
+#pragma unroll
+    for (int i = 0; i < M / 2; i++) { const double2 t = s[i]; x[2 * i] = t.x; x[2 * i + 1] = t.y; }
+}
+template <int M>
+__device__ __forceinline__ void ln_store_samples(double* dst, const double* x, int lane) {
+    double2* s = reinterpret_cast<double2*>(dst + M * lane);
+#pragma unroll
+    for (int i = 0; i < M / 2; i++) s[i] = make_double2(x[2 * i], x[2 * i + 1]);
+}
+
+template <int NP>
+__device__ __forceinline__ void ln_load_taps(const FilterDev* filt, double (&a)[NP], double (&b)[NP]) {
+#pragma unroll
+    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    if constexpr (NP <= 16) {   // the same in every lane: scalar registers
+#pragma unroll
+        for (int j = 0; j < NP; j++) { a[j] = w1d_uniform(a[j]); b[j] = w1d_uniform(b[j]); }
+    }
+}
+
+// The error on one coefficient from its value and rank (kb_delta_home of the streamed path, same expression).
+struct LineGini {
+    double f, g, inv_g2, n;
+    __device__ __forceinline__ double delta(double y, unsigned rank) const {
+        const double sg = sign_ref(y);
+        const double coef = (y != 0.0) ? 2.0 * (double)rank - n - 1.0 : 0.0;
+        const double df = coef * sg;
+        return -(df * g - f * (n * sg)) * inv_g2;
+    }
+};
+
+#define LN_BOUNDS(T) __launch_bounds__(T, (NP > 16 ? 1 : 2))
+
+// ---- columns: contiguous lines of 64 M samples ---------------------------------------------------------
+// grid (workgroups per example, examples), 64 threads.  in/Y/P: chunk arrays, example stride xs, column c
+// of an example at c * 64 M.  P may be null.
+template <int NP, int M>
+__global__ LN_BOUNDS(64) void kc_fwd_cols(const double* __restrict__ in, double* __restrict__ Y, double* __restrict__ P, size_t xs,
+                                          int ncols, const FilterDev* filt) {
+    const int lane = threadIdx.x;
+    double a[NP], b[NP];
+    ln_load_taps<NP>(filt, a, b);
+    const size_t off = (size_t)blockIdx.y * xs;
+    for (int c = blockIdx.x; c < ncols; c += gridDim.x) {
+        const size_t lo = off + (size_t)c * (64 * M);
+        LinePyramid<M> p;
+        LineLane<M> y;
+        double small_lo;
+        ln_load_samples<M>(in + lo, p.x, lane);
+        ln_forward<NP, M>(p, a, b, lane, y, small_lo);
+        ln_store<M>(Y + lo, y.v, y.v[0], lane);
+        if (P) ln_store<M>(P + lo, p.lo, small_lo, lane);
+    }
+}
+
+// Errors on the coefficients of the columns and the columns themselves (in) -> errors on the columns
+// (out, may be null: last pass) and the window sums of the filter gradient, added to
+// partial[(example * LN_GX + workgroup) * 2 NP + u] as the level kernels do.  The errors on the
+// coefficients are read from coef, or with FROM_RANKS computed on the way in from the coefficients
+// (coef), their ranks and the example's sums fg = {f, g}: the array of errors is then never written.
+// ranks: per slice of `slice` examples an array of slice * n ranks at ranks + slice_first_example * n
+// DOUBLES (the streamed path's layout).
+template <int NP, int M, bool FROM_RANKS>
+__global__ LN_BOUNDS(64) void kc_bwd_cols(const double* __restrict__ coef, const double* __restrict__ in, double* __restrict__ out,
+                                          size_t xs, int ncols, const FilterDev* filt, double* partial, const double* ranks,
+                                          int slice, const double* fg) {
+    const int lane = threadIdx.x;
+    double a[NP], b[NP];
+    ln_load_taps<NP>(filt, a, b);
+    double gL[NP], gH[NP];
+#pragma unroll
+    for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
+    const size_t off = (size_t)blockIdx.y * xs;
+    LineGini gini{0, 0, 0, (double)xs};
+    const unsigned* rk = nullptr;
+    if constexpr (FROM_RANKS) {
+        const int e = blockIdx.y, e0 = (e / slice) * slice;
+        rk = reinterpret_cast<const unsigned*>(ranks + (size_t)e0 * xs) + (size_t)(e - e0) * xs;
+        gini.f = fg[2 * e];
+        gini.g = fg[2 * e + 1];
+        gini.inv_g2 = 1.0 / (gini.g * gini.g);
+    }
+    for (int c = blockIdx.x; c < ncols; c += gridDim.x) {
+        const size_t lo = off + (size_t)c * (64 * M);
+        LinePyramid<M> p;
+        LineLane<M> unused_y, dy;
+        double unused_lo;
+        ln_load_samples<M>(in + lo, p.x, lane);
+        ln_forward<NP, M>(p, a, b, lane, unused_y, unused_lo);
+        ln_load<M>(coef + lo, dy, lane);          // errors on the coefficients, or the coefficients themselves
+        if constexpr (FROM_RANKS) {
+            const unsigned* rc = rk + (size_t)c * (64 * M);
+            dy.v[0] = gini.delta(dy.v[0], rc[lane]);
+            dy.v[1] = gini.delta(dy.v[1], rc[64 + lane]);
+#pragma unroll
+            for (int cc = 2; cc < M; cc *= 2) {
+#pragma unroll
+                for (int m = 0; m < cc; m++) dy.v[cc + m] = gini.delta(dy.v[cc + m], rc[64 * cc + cc * lane + m]);
+            }
+        }
+        double dtop[M];
+        if (out) {
+            ln_backward<NP, M, true>(p, dy, dtop, a, b, gL, gH, lane);
+            ln_store_samples<M>(out + lo, dtop, lane);
+        } else {
+            ln_backward<NP, M, false>(p, dy, dtop, a, b, gL, gH, lane);
+        }
+    }
+    double* part = partial + ((size_t)blockIdx.y * LN_GX + blockIdx.x) * 2 * NP;
+#pragma unroll
+    for (int u = 0; u < NP; u++) {
+        double sl = gL[u], sh = gH[u];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sl += __shfl_xor(sl, o, 64); sh += __shfl_xor(sh, o, 64); }
+        if (lane == 0) { part[u] += sl; part[NP + u] += sh; }
+    }
+}
+
+// ---- rows: lines of 64 M samples strided by the number of rows -------------------------------------------
+// Tile: ROWS rows x 64 M columns in LDS, row stride RS doubles, element c of a row at c + c / M: a lane's M
+// samples sit M + 1 doubles from its neighbour's (conflict-free 8-byte reads), and the row pairs x columns
+// that half a wave moves on the global side fall into 32 different banks (row stride = 2 or 4 mod 32).
+template <int M>
+struct LineTile {
+    static constexpr int ROWS = (M == 16) ? 8 : 16;
+    static constexpr int RS = 64 * (M + 1) + (ROWS == 16 ? 2 : 4);
+    static constexpr size_t BYTES = (size_t)ROWS * RS * sizeof(double);
+    static constexpr int PAIRS = ROWS / 2, COLS_PER_STEP = 256 / PAIRS, STEPS = 64 * M / COLS_PER_STEP;
+    __device__ static __forceinline__ int pad(int c) { return c + c / M; }
+};
+
+// ROWS adjacent rows of one example between memory (element (r, c) at r + R c) and the tile; 256 threads
+template <int M, bool TO_TILE>
+__device__ __forceinline__ void ln_move_tile(double* tile, double* mem, int R) {
+    using T = LineTile<M>;
+    const int rp = threadIdx.x % T::PAIRS;
+#pragma unroll 4
+    for (int it = 0; it < T::STEPS; it++) {
+        const int c = threadIdx.x / T::PAIRS + T::COLS_PER_STEP * it;
+        double2* g = reinterpret_cast<double2*>(mem + 2 * rp + (size_t)R * c);
+        double* t = tile + (2 * rp) * T::RS + T::pad(c);
+        if constexpr (TO_TILE) {
+            const double2 v = *g;
+            t[0] = v.x;
+            t[T::RS] = v.y;
+        } else {
+            *g = make_double2(t[0], t[T::RS]);
+        }
+    }
+}
+// one row of the tile <-> samples / lane layout
+template <int M>
+__device__ __forceinline__ void ln_row_samples(const double* row, double* x, int lane) {
+#pragma unroll
+    for (int i = 0; i < M; i++) x[i] = row[(M + 1) * lane + i];
+}
+template <int M>
+__device__ __forceinline__ void ln_row_store(double* row, const LineLane<M>& y, int lane) {
+    row[LineTile<M>::pad(lane)] = y.v[0];
+#pragma unroll
+    for (int c = 1; c < M; c *= 2) {
+#pragma unroll
+        for (int m = 0; m < c; m++) row[LineTile<M>::pad(64 * c + c * lane + m)] = y.v[c + m];
+    }
+}
+template <int M>
+__device__ __forceinline__ void ln_row_load(const double* row, LineLane<M>& y, int lane) {
+    y.v[0] = row[LineTile<M>::pad(lane)];
+#pragma unroll
+    for (int c = 1; c < M; c *= 2) {
+#pragma unroll
+        for (int m = 0; m < c; m++) y.v[c + m] = row[LineTile<M>::pad(64 * c + c * lane + m)];
+    }
+}
+
+// Forward over the rows: grid (tiles per example <= R / ROWS, examples), 256 threads, LineTile<M>::BYTES of LDS.
+template <int NP, int M>
+__global__ LN_BOUNDS(256) void kr_fwd_rows(const double* __restrict__ in, double* __restrict__ Y, size_t xs, int R,
+                                           const FilterDev* filt) {
+    using T = LineTile<M>;
+    extern __shared__ __attribute__((aligned(16))) double ln_tile[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double a[NP], b[NP];
+    ln_load_taps<NP>(filt, a, b);
+    for (int tile = blockIdx.x; tile < R / T::ROWS; tile += gridDim.x) {
+        const size_t base = (size_t)blockIdx.y * xs + (size_t)tile * T::ROWS;
+        __syncthreads();
+        ln_move_tile<M, true>(ln_tile, const_cast<double*>(in) + base, R);
+        __syncthreads();
+        for (int j = wave; j < T::ROWS; j += 4) {
+            double* row = ln_tile + j * T::RS;
+            LinePyramid<M> p;
+            LineLane<M> y;
+            double unused_lo;
+            ln_row_samples<M>(row, p.x, lane);
+            ln_forward<NP, M>(p, a, b, lane, y, unused_lo);
+            ln_row_store<M>(row, y, lane);      // in place: the row is in this wave's registers
+        }
+        __syncthreads();
+        ln_move_tile<M, false>(ln_tile, Y + base, R);
+    }
+}
+
+// Filter gradient over the rows (no errors on the input: the last pass of the training step): errors on
+// the row coefficients (coef) and the rows themselves (in).  grid (tiles per example <= LN_GX, examples).
+template <int NP, int M>
+__global__ LN_BOUNDS(256) void kr_grad_rows(const double* __restrict__ coef, const double* __restrict__ in, size_t xs, int R,
+                                            const FilterDev* filt, double* partial) {
+    using T = LineTile<M>;
+    constexpr int PER_WAVE = T::ROWS / 4;
+    extern __shared__ __attribute__((aligned(16))) double ln_tile[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double a[NP], b[NP];
+    ln_load_taps<NP>(filt, a, b);
+    double gL[NP], gH[NP];
+#pragma unroll
+    for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
+    for (int tile = blockIdx.x; tile < R / T::ROWS; tile += gridDim.x) {
+        const size_t base = (size_t)blockIdx.y * xs + (size_t)tile * T::ROWS;
+        double xr[PER_WAVE][M];
+        __syncthreads();
+        ln_move_tile<M, true>(ln_tile, const_cast<double*>(in) + base, R);
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < PER_WAVE; jj++) ln_row_samples<M>(ln_tile + (wave + 4 * jj) * T::RS, xr[jj], lane);
+        __syncthreads();
+        ln_move_tile<M, true>(ln_tile, const_cast<double*>(coef) + base, R);
+        __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < PER_WAVE; jj++) {
+            LinePyramid<M> p;
+            LineLane<M> unused_y, dy;
+            double unused_lo, dtop[M];
+#pragma unroll
+            for (int i = 0; i < M; i++) p.x[i] = xr[jj][i];
+            ln_forward<NP, M>(p, a, b, lane, unused_y, unused_lo);
+            ln_row_load<M>(ln_tile + (wave + 4 * jj) * T::RS, dy, lane);
+            ln_backward<NP, M, false>(p, dy, dtop, a, b, gL, gH, lane);
+        }
+    }
+    __syncthreads();                        // the tile is free: sums of the four waves
+    double* red = ln_tile;
+#pragma unroll
+    for (int u = 0; u < NP; u++) {
+        double sl = gL[u], sh = gH[u];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sl += __shfl_xor(sl, o, 64); sh += __shfl_xor(sh, o, 64); }
+        if (lane == 0) { red[wave * 2 * NP + u] = sl; red[wave * 2 * NP + NP + u] = sh; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * NP) {
+        double s = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) s += red[w * 2 * NP + threadIdx.x];
+        partial[((size_t)blockIdx.y * LN_GX + blockIdx.x) * 2 * NP + threadIdx.x] += s;
+    }
+}
+
+}  // namespace wn

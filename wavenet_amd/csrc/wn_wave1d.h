@@ -39,10 +39,10 @@ __device__ __forceinline__ double w1d_uniform(double v) {
                             __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
-// The lane's M values with HL values of the lanes before it and HR of the lanes after it:
-// ext[HL + i] = own[i]; ext[HL - 1 - t] and ext[HL + M + t] continue the sequence on either side.
+// The lane's M values (own[M]) with HL values of the lanes before it and HR of the lanes after it in
+// ext[HL + M + HR]: ext[HL + i] = own[i]; ext[HL - 1 - t] and ext[HL + M + t] continue the sequence on either side.
 template <int M, int HL, int HR>
-__device__ __forceinline__ void w1d_extend(const double (&own)[M], double (&ext)[HL + M + HR], int lane) {
+__device__ __forceinline__ void w1d_extend(const double* own, double* ext, int lane) {
 #pragma unroll
     for (int i = 0; i < M; i++) ext[HL + i] = own[i];
 #pragma unroll
@@ -98,10 +98,11 @@ __device__ __forceinline__ void w1d_extend(const double (&own)[M], double (&ext)
 
 // ---- forward (src/Wavenet.cxx:404-445) ----------------------------------------------------------------
 
-// One level with M input samples per lane: lo[m], hi[m] = outputs M/2 * lane + m.
+// One level with M input samples per lane (in[M]): lo[m], hi[m] (M/2 each) = outputs M/2 * lane + m.
+// All arrays are indexed with compile-time constants only, so they stay in registers.
 template <int NP, int M>
-__device__ __forceinline__ void w1d_fwd_block(const double (&in)[M], double (&lo)[M / 2], double (&hi)[M / 2],
-                                              const double (&a)[NP], const double (&b)[NP], int lane) {
+__device__ __forceinline__ void w1d_fwd_block(const double* in, double* lo, double* hi, const double (&a)[NP],
+                                              const double (&b)[NP], int lane) {
     constexpr int H = NP / 2 - 1;
     double ext[H + M + H];
     w1d_extend<M, H, H>(in, ext, lane);
@@ -147,9 +148,9 @@ __device__ __forceinline__ void w1d_fwd_small(double in, double& lo, double& hi,
 // per lane.  Accumulates the filter-gradient correlation; with PROP, out receives the errors on the
 // level's input, 2 MR per lane.
 template <int NP, int MR, bool PROP>
-__device__ __forceinline__ void w1d_bwd_block(const double (&dlo)[MR], const double (&dhi)[MR], const double (&act)[2 * MR],
-                                              double (&out)[2 * MR], const double (&a)[NP], const double (&b)[NP],
-                                              double (&gL)[NP], double (&gH)[NP], int lane) {
+__device__ __forceinline__ void w1d_bwd_block(const double* dlo, const double* dhi, const double* act, double* out,
+                                              const double (&a)[NP], const double (&b)[NP], double (&gL)[NP], double (&gH)[NP],
+                                              int lane) {
     {
         constexpr int H = NP / 2 - 1;
         double ext[H + 2 * MR + H];
