@@ -252,3 +252,31 @@ def test_forward_coefficients_only(ctx, R, C, N):
     ctx.forward(dX, B, R, C, dY2, dPr, dY1, dPc)
     torch.cuda.synchronize()
     assert torch.allclose(dY, dY2, rtol=1e-13, atol=1e-15)
+
+
+def test_slices_of_the_chunk_do_not_change_the_examples(ctx):
+    """260 images of 512x512 are more than one sort covers (2^26 coefficients per slice): every example's
+    gradient and cost must come out the same as when the batch is handed over in two halves of one slice
+    each, and the batch sums must agree."""
+    import torch
+    from wavenet_amd import generators as G
+    R = C = 512
+    N, B = 4, 260
+    ctx.set_filter(filt_for(N, 5))
+    n = R * C
+    dX = torch.empty(B * n, dtype=torch.float64, device="cuda")
+    ctx.generate_calorimeter(dX, B, R, C, seed=77, first=0)
+    dG, dS = dev_empty(B * N), dev_empty(B)
+    ctx.train_batch(dX, B, R, C, dG, dS)
+    sums = ctx.sums().copy()
+    G1, S1 = dG.cpu().numpy().copy(), dS.cpu().numpy().copy()
+    half = B // 2
+    dG2, dS2 = dev_empty(B * N), dev_empty(B)
+    ctx.train_batch(dX, half, R, C, dG2, dS2)
+    s_a = ctx.sums().copy()
+    ctx.train_batch(dX[half * n:], B - half, R, C, dG2[half * N:], dS2[half:])
+    s_b = ctx.sums().copy()
+    assert np.array_equal(G1, dG2.cpu().numpy())
+    assert np.array_equal(S1, dS2.cpu().numpy())
+    assert sums[-1] == 0
+    assert relerr(sums[:-1], (s_a + s_b)[:-1]) < 1e-12
