@@ -55,9 +55,12 @@ enum {
 typedef struct wn_context wn_context;
 
 /* ---- context ---------------------------------------------------------------------------- */
-/* One context per device and caller thread.  Environment read here: WAVENET_HIP_WAVE64=0 keeps the
- * 64x64 examples on the workgroup-per-example kernels (the default for that shape are kernels that
- * give each example to one wave and hold the image in registers). */
+/* One context per device and caller thread.  Environment read here: WAVENET_HIP_WAVE64=0 switches the
+ * one-wave kernels off -- those that give a 64x64 image, a 1024-sample signal or (in larger images, up to
+ * 8 taps) a line of 128 ... 1024 samples to one wave and hold it in registers -- and keeps every shape on
+ * the workgroup-per-example and level-by-level kernels (same results to rounding; a comparison hook).
+ * WAVENET_HIP_EXACT_SORT=1 makes examples beyond 4096 samples rank with two 64-bit radix sorts instead of
+ * one sort of 32-bit keys plus the exact re-ranking of equal keys (same ranks). */
 int wn_create(int device, wn_context** ctx);
 int wn_destroy(wn_context* ctx);
 /* A context starts on a stream of its own.  This switches it to the caller's hipStream_t (e.g. the
