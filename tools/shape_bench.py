@@ -30,5 +30,5 @@ for _ in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / steps
 print(f"{R}x{C} N={N} batch {B}: {dt * 1e3:.3f} ms per step, {B / dt:.0f} examples/s, "
-      f"{B * 120 * R * C / dt / 8e12:.3f} of the roofline", flush=True)
+      f"{B * (120 if (R > 1 and C > 1) else 64) * R * C / dt / 8e12:.3f} of the roofline", flush=True)
 ctx.close()
