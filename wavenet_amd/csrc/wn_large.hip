@@ -19,17 +19,19 @@
 extern "C" const void* wn_kernel_lines_np2(int kind, int M);
 extern "C" const void* wn_kernel_lines_np4(int kind, int M);
 extern "C" const void* wn_kernel_lines_np8(int kind, int M);
+extern "C" const void* wn_kernel_lines_np16(int kind, int M);
 
 namespace wn {
 namespace {
 
-// One-wave-per-line kernels (wn_lines.h, compiled per tap count in wn_lines_np.hip, up to 8 taps).
+// One-wave-per-line kernels (wn_lines.h, compiled per tap count in wn_lines_np.hip, up to 16 taps).
 enum { LN_FWD_COLS = 0, LN_BWD_COLS = 1, LN_BWD_COLS_RANKS = 2, LN_FWD_ROWS = 3, LN_GRAD_ROWS = 4 };
 const void* line_kernel(int np, int kind, int M) {
     switch (np) {
         case 2: return wn_kernel_lines_np2(kind, M);
         case 4: return wn_kernel_lines_np4(kind, M);
         case 8: return wn_kernel_lines_np8(kind, M);
+        case 16: return wn_kernel_lines_np16(kind, M);
     }
     return nullptr;
 }
@@ -803,13 +805,16 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         double* YD = Yout ? Yout + (size_t)e0 * n : pl.YD;
         // Lines of 128 .. 1024 samples go through the one-wave-per-line kernels (wn_lines.h): rows in tiles of
         // 16 (8) adjacent rows through LDS, columns directly.  No pyramid is written unless the caller asked
-        // for it -- the backward kernels rebuild it in registers.  Up to 8 taps: beyond, the cross-lane halos and
-        // the replicated small levels of the register cascade cost more than the extra passes of the level
-        // kernels (measured at 512x512: 8 taps 21.6 against 28.3 ms, 16 taps 38.0 against 36.1, 32 taps 53 against 30).
+        // for it -- the backward kernels rebuild it in registers.  Rows up to 8 taps, columns up to 16 (at 16 for lines
+        // of 256 and 512 only: measured neutral at 1024, slower at 128): beyond,
+        // the cross-lane halos and the replicated small levels of the register cascade cost more than the extra
+        // passes of the level kernels (measured at 512x512, ms per 1024 images, line kernels against level
+        // kernels: 8 taps 21.6 / 28.3; 16 taps, columns only 31.7, rows only 42.6, neither 36.1; 32 taps, 512
+        // images: columns only 34.1, rows only 48.9, neither 29.7).
         const int R = 1 << lgR, C = 1 << lgC;
         const int Mrow = C / 64, Mcol = R / 64;     // samples per lane
         const bool rowLines = (NP <= 8 && lgC >= 7 && lgC <= 10 && R >= line_tile_rows(Mrow) && ctx->wave64 && !ProwOut);
-        const bool colLines = (NP <= 8 && lgR >= 7 && lgR <= 10 && lgC > 0 && ctx->wave64);
+        const bool colLines = ((NP <= 8 || (NP == 16 && (lgR == 8 || lgR == 9))) && lgR >= 7 && lgR <= 10 && lgC > 0 && ctx->wave64);
         const double* Yc = YD;
         double* pcolArg = PcolOut ? Pcol : nullptr;
         size_t xs = n;
