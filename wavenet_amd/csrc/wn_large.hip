@@ -221,6 +221,121 @@ __global__ __launch_bounds__(BT) void kb_bwd_level(const double* __restrict__ lp
     }
 }
 
+// ---- level kernels for contiguous lines, operands staged in LDS ------------------------------------------
+// For lines whose samples are contiguous (the column pass; 1D signals) a thread of the kernels above loads
+// its N taps' worth of operands itself, 8 bytes at a 16-byte stride across the wave: at 16 and 32 taps that
+// is bound by L1 requests.  Here a workgroup produces LT consecutive outputs of one line: it stages the
+// 2 LT + N - 1 operands in LDS with coalesced loads and every thread reads its window from there, two
+// doubles per instruction (the window of output k starts at the even offset 2 k).
+constexpr int LT = 256;   // outputs per workgroup = threads
+constexpr int LDS_LEVEL_TAPS = 16;   // from this compiled tap count on
+
+template <int NP>
+__device__ __forceinline__ void stage_window(double* tile, const double* __restrict__ line, int first, int mask) {
+    // tile[t] = line[(first + t) & mask], t < 2 LT + NP (one more than needed keeps the pairs whole)
+    for (int t = threadIdx.x; t < 2 * LT + NP; t += LT) tile[t] = line[(first + t) & mask];
+}
+// the window of thread tid in ascending order: win[u] = tile[2 tid + u] = operand of tap NP - 1 - u
+template <int NP>
+__device__ __forceinline__ void read_window(const double* tile, double (&win)[NP]) {
+    const double2* p = reinterpret_cast<const double2*>(tile + 2 * threadIdx.x);
+#pragma unroll
+    for (int u = 0; u < NP / 2; u++) { const double2 t = p[u]; win[2 * u] = t.x; win[2 * u + 1] = t.y; }
+}
+
+// kb_fwd_level for contiguous lines with at least LT outputs: grid (lines * half / LT, examples)
+template <int NP>
+__global__ __launch_bounds__(LT) void kb_fwd_level_lds(const double* __restrict__ in, double* __restrict__ lo, double* __restrict__ hi,
+                                                       size_t xs, Geom g, int lgHalf, const FilterDev* filt) {
+    __shared__ __attribute__((aligned(16))) double tile[2 * LT + NP];
+    double a[NP], b[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    const int w0 = blockIdx.x * LT;
+    const int line = w0 >> lgHalf, k0 = w0 & ((1 << lgHalf) - 1);
+    const size_t off = (size_t)blockIdx.y * xs + (size_t)line * g.ls;
+    stage_window<NP>(tile, in + off, 2 * k0 + NP / 2 - (NP - 1), (2 << lgHalf) - 1);
+    __syncthreads();
+    double win[NP];
+    read_window<NP>(tile, win);
+    double sl = 0, sh = 0;
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        sl = __builtin_fma(a[j], win[NP - 1 - j], sl);
+        sh = __builtin_fma(b[j], win[NP - 1 - j], sh);
+    }
+    lo[off + k0 + threadIdx.x] = sl;
+    hi[off + k0 + threadIdx.x] = sh;
+}
+
+// kb_bwd_level / kb_grad_level (PROP false) for contiguous lines with at least LT errors per line:
+// grid (workgroups per example <= GXMAX, examples); a workgroup walks over tiles of LT errors.
+template <int NP, bool PROP>
+__global__ __launch_bounds__(LT) void kb_bwd_level_lds(const double* __restrict__ lp, const double* __restrict__ hp,
+                                                       const double* __restrict__ act, double* __restrict__ out, size_t xs, Geom g,
+                                                       int lgLen, const FilterDev* filt, double* partial) {
+    constexpr int S = NP / 2;
+    constexpr int JE = S & 1, JO = (S + 1) & 1;
+    constexpr int CE = (JE - S) / 2, CO = (1 + JO - S) / 2;
+    constexpr int CMIN = CE < CO ? CE : CO;
+    constexpr int EW = LT + NP / 2 + 1;                  // errors a tile's propagation reads
+    __shared__ __attribute__((aligned(16))) double tile[2 * LT + NP];
+    __shared__ double tl[PROP ? EW : 1], th[PROP ? EW : 1];
+    __shared__ double red[(LT / 64) * 2 * NP];
+    double a[NP], b[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    double gL[NP], gH[NP];
+#pragma unroll
+    for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
+    const int tid = threadIdx.x;
+    const int W = 1 << (g.lgNL + lgLen), rmask = (1 << lgLen) - 1;
+    for (int w0 = blockIdx.x * LT; w0 < W; w0 += gridDim.x * LT) {
+        const int line = w0 >> lgLen, r0 = w0 & rmask;
+        const size_t off = (size_t)blockIdx.y * xs + (size_t)line * g.ls;
+        __syncthreads();
+        stage_window<NP>(tile, act + off, 2 * r0 + NP / 2 - (NP - 1), (2 << lgLen) - 1);
+        if constexpr (PROP) {
+            for (int t = tid; t < EW; t += LT) {
+                tl[t] = lp[off + ((r0 + CMIN + t) & rmask)];
+                th[t] = hp[off + ((r0 + CMIN + t) & rmask)];
+            }
+        }
+        __syncthreads();
+        const double dl = lp[off + r0 + tid], dh = hp[off + r0 + tid];
+        double win[NP];
+        read_window<NP>(tile, win);
+#pragma unroll
+        for (int u = 0; u < NP; u++) {
+            gL[u] = __builtin_fma(dl, win[NP - 1 - u], gL[u]);
+            gH[u] = __builtin_fma(dh, win[NP - 1 - u], gH[u]);
+        }
+        if constexpr (PROP) {
+            double se = 0, so = 0;
+#pragma unroll
+            for (int i = 0; i < NP / 2; i++) {
+                se = __builtin_fma(a[JE + 2 * i], tl[tid + i + CE - CMIN], se);
+                se = __builtin_fma(b[JE + 2 * i], th[tid + i + CE - CMIN], se);
+                so = __builtin_fma(a[JO + 2 * i], tl[tid + i + CO - CMIN], so);
+                so = __builtin_fma(b[JO + 2 * i], th[tid + i + CO - CMIN], so);
+            }
+            *reinterpret_cast<double2*>(out + off + 2 * (r0 + tid)) = make_double2(se, so);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NP; u++) {
+        const double sl = wave_sum(gL[u]), sh = wave_sum(gH[u]);
+        if ((tid & 63) == 0) { red[(tid >> 6) * 2 * NP + u] = sl; red[(tid >> 6) * 2 * NP + NP + u] = sh; }
+    }
+    __syncthreads();
+    if (tid < 2 * NP) {
+        double s = 0;
+#pragma unroll
+        for (int wv = 0; wv < LT / 64; wv++) s += red[wv * 2 * NP + tid];
+        partial[((size_t)blockIdx.y * GXMAX + blockIdx.x) * 2 * NP + tid] += s;
+    }
+}
+
 // Per-example gradient from the per-workgroup window sums: tap k collects gL[k] and (-1)^(N-1-k) gH[N-1-k].
 __global__ void kb_grad_finish(const double* partial, int NP, const FilterDev* filt, double* grad_e) {
     const int ex = blockIdx.x, kp = threadIdx.x;
@@ -587,6 +702,11 @@ int fwd_pass_big(wn_context* ctx, const double* in, double* P, double* out, int 
     }
     for (int i = g.lgLen - 1; i >= 0; i--) {
         const double* src = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i) * g.es;
+        if (NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && (1 << i) >= LT) {
+            hipLaunchKernelGGL(kb_fwd_level_lds<NP>, dim3((1u << (g.lgNL + i)) / LT, B), dim3(LT), 0, st, src,
+                               P + (size_t)(1 << i), out + (size_t)(1 << i), n, g, i, ctx->dfilt);
+            continue;
+        }
         hipLaunchKernelGGL(kb_fwd_level<NP>, grid_for(1 << (g.lgNL + i), B), dim3(BT), 0, st, src,
                            P + (size_t)(1 << i) * g.es, out + (size_t)(1 << i) * g.es, n, g, i, ctx->dfilt);
     }
@@ -607,6 +727,19 @@ int bwd_pass_big(wn_context* ctx, const double* coef, const double* in, const do
     for (int i = 0; i < g.lgLen; i++) {
         const double* hp = coef + (size_t)(1 << i) * g.es;
         const bool propagate = (i != g.lgLen - 1 || lastPropagate);
+        if (partial && NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && (1 << i) >= LT) {
+            const double* act = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i);
+            const dim3 grid((unsigned)std::min<size_t>(((size_t)1 << (g.lgNL + i)) / LT, GXMAX), B);
+            if (propagate) {
+                hipLaunchKernelGGL((kb_bwd_level_lds<NP, true>), grid, dim3(LT), 0, st, lp, hp, act, dst, n, g, i, ctx->dfilt, partial);
+                lp = dst;
+                dst = (dst == pingA) ? pingB : pingA;
+            } else {
+                hipLaunchKernelGGL((kb_bwd_level_lds<NP, false>), grid, dim3(LT), 0, st, lp, hp, act, (double*)nullptr, n, g, i, ctx->dfilt,
+                                   partial);
+            }
+            continue;
+        }
         if (partial && propagate) {
             const double* act = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i) * g.es;
             hipLaunchKernelGGL(kb_bwd_level<NP>, grid_for(1 << (g.lgNL + i), B, GXMAX), dim3(BT), 0, st, lp, hp, act, dst, n, g, i,
