@@ -228,7 +228,10 @@ __global__ __launch_bounds__(BT) void kb_bwd_level(const double* __restrict__ lp
 // 2 LT + N - 1 operands in LDS with coalesced loads and every thread reads its window from there, two
 // doubles per instruction (the window of output k starts at the even offset 2 k).
 constexpr int LT = 256;   // outputs per workgroup = threads
-constexpr int LDS_LEVEL_TAPS = 16;   // from this compiled tap count on
+#ifndef WN_LDS_LEVEL_TAPS
+#define WN_LDS_LEVEL_TAPS 16
+#endif
+constexpr int LDS_LEVEL_TAPS = WN_LDS_LEVEL_TAPS;   // from this compiled tap count on
 
 template <int NP>
 __device__ __forceinline__ void stage_window(double* tile, const double* __restrict__ line, int first, int mask) {
