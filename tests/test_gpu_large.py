@@ -280,3 +280,31 @@ def test_slices_of_the_chunk_do_not_change_the_examples(ctx):
     assert np.array_equal(S1, dS2.cpu().numpy())
     assert sums[-1] == 0
     assert relerr(sums[:-1], (s_a + s_b)[:-1]) < 1e-12
+
+
+@pytest.mark.parametrize("R,C,N", [(512, 512, 4), (256, 128, 8), (512, 256, 16), (128, 1024, 2), (1024, 256, 6)])
+def test_line_kernels_against_level_kernels(ctx, R, C, N):
+    """The same batch through the one-wave-per-line kernels (default) and, with the one-wave kernels switched
+    off, level by level: per-example gradients and costs agree to rounding, the batch sums too."""
+    import torch
+    from wavenet_amd import generators as G
+    B = 5
+    X = G.calorimeter(B, R, C, seed=R + C + N)
+    a = filt_for(N, 6)
+    dX = to_dev(X)
+    ctx.set_filter(a)
+    dG, dS = dev_empty(B * N), dev_empty(B)
+    ctx.train_batch(dX, B, R, C, dG, dS)
+    sums = ctx.sums().copy()
+    plain = _ctx_with_env("WAVENET_HIP_WAVE64", "0")
+    try:
+        plain.set_filter(a)
+        dG2, dS2 = dev_empty(B * N), dev_empty(B)
+        plain.train_batch(dX, B, R, C, dG2, dS2)
+        sums2 = plain.sums().copy()
+        torch.cuda.synchronize()
+    finally:
+        plain.close()
+    assert relerr(dG.cpu().numpy(), dG2.cpu().numpy()) < 1e-11
+    assert np.abs(dS.cpu().numpy() / dS2.cpu().numpy() - 1).max() < 1e-12
+    assert relerr(sums[:N + 1], sums2[:N + 1]) < 1e-11 and sums[N + 1] == sums2[N + 1] == 0
