@@ -474,10 +474,15 @@ __global__ __launch_bounds__(BT) void kb_count_nonzero(const double* Y, unsigned
     }
 }
 // counts[b] -> number of non-zeros before workgroup b (in place); segs[2e], segs[2e+1] = first sorted
-// position and number of non-zeros of example e (bpe workgroups each); *total = all of them.  One workgroup.
-__global__ __launch_bounds__(BT) void kb_scan_counts(unsigned* counts, int nblocks, int bpe, int Bs, unsigned* segs, unsigned* total) {
+// position and number of non-zeros of example e (bpe workgroups each); *total = all of them.  One workgroup
+// per slice of `slice` examples (the last one may be shorter); the arguments describe the whole chunk.
+__global__ __launch_bounds__(BT) void kb_scan_counts(unsigned* counts, int bpe, int B, int slice, unsigned* segs, unsigned* total) {
     __shared__ unsigned part[BT];
     const int tid = threadIdx.x;
+    const int e0 = blockIdx.x * slice, Bs = min(slice, B - e0), nblocks = Bs * bpe;
+    counts += (size_t)e0 * bpe;
+    segs += 2 * (size_t)e0;
+    total += blockIdx.x;
     const int per = (nblocks + BT - 1) / BT;
     const int b0 = tid * per, b1 = min(b0 + per, nblocks);
     unsigned sum = 0;
@@ -823,12 +828,8 @@ int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, dou
     unsigned* totals = segs + 2 * (size_t)B;
     const int nslices = (B + slice - 1) / slice;
     unsigned* flag = totals + nslices;
-    for (int e0 = 0, sl = 0; e0 < B; e0 += slice, sl++) {
-        const int Bs = std::min(slice, B - e0);
-        unsigned* counts = cnt + (size_t)e0 * bpe;
-        hipLaunchKernelGGL(kb_count_nonzero, dim3(Bs * bpe), dim3(BT), 0, st, Y + (size_t)e0 * n, counts);
-        hipLaunchKernelGGL(kb_scan_counts, dim3(1), dim3(BT), 0, st, counts, Bs * bpe, bpe, Bs, segs + 2 * (size_t)e0, totals + sl);
-    }
+    hipLaunchKernelGGL(kb_count_nonzero, dim3((unsigned)B * bpe), dim3(BT), 0, st, Y, cnt);
+    hipLaunchKernelGGL(kb_scan_counts, dim3(nslices), dim3(BT), 0, st, cnt, bpe, B, slice, segs, totals);
     WN_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(unsigned), st));
     const int gx = (int)std::min<size_t>(n / FIX_TILE, GXMAX);
     std::vector<unsigned> nonzero(nslices);
