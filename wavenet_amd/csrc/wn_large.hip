@@ -456,6 +456,7 @@ constexpr unsigned GROUP_LIMIT = 1024;
 // the re-ranking of equal keys than the pass saves -- smooth 2^20-sample signals put dozens of coefficients on each key.
 constexpr int KEY_E0 = 1023 - 95;
 constexpr int CP_ITEMS = 8, CP_BLOCK = BT * CP_ITEMS;
+static_assert(CP_BLOCK == 2048, "kc_fwd_cols (wn_lines.h) counts non-zeros per 2048 coefficients");
 
 __global__ __launch_bounds__(BT) void kb_count_nonzero(const double* Y, unsigned* counts) {
     __shared__ unsigned wsum[BT / 64];
@@ -806,10 +807,11 @@ int gini_big(wn_context* ctx, const double* Y, double* D, int B, size_t n, doubl
 // sorted in slices of at most 2^23 coefficients (32 examples of 512x512, 8 signals of 2^20 samples).
 int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB,
                unsigned* idxA, unsigned* idxB, unsigned* cnt, double* gpart, double* fg, double* S_e, void* sort_tmp,
-               size_t sort_tmp_bytes, int* rank_slice = nullptr) {
+               size_t sort_tmp_bytes, int* rank_slice = nullptr, bool counts_ready = false) {
     // rank_slice (with D null): receives the number of examples per slice when the ranks were left in keysB
     // (slice s at keysB + s * slice * n, as 32-bit ranks at home positions) for a consumer that computes
     // the errors itself, 0 when this path did not apply and only the sums were computed.
+    // counts_ready: cnt already holds the non-zero count of every CP_BLOCK coefficients of the chunk.
     if (rank_slice) *rank_slice = 0;
     int lgn = 0;
     while (((size_t)1 << lgn) < n) lgn++;
@@ -828,7 +830,7 @@ int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, dou
     unsigned* totals = segs + 2 * (size_t)B;
     const int nslices = (B + slice - 1) / slice;
     unsigned* flag = totals + nslices;
-    hipLaunchKernelGGL(kb_count_nonzero, dim3((unsigned)B * bpe), dim3(BT), 0, st, Y, cnt);
+    if (!counts_ready) hipLaunchKernelGGL(kb_count_nonzero, dim3((unsigned)B * bpe), dim3(BT), 0, st, Y, cnt);
     hipLaunchKernelGGL(kb_scan_counts, dim3(nslices), dim3(BT), 0, st, cnt, bpe, B, slice, segs, totals);
     WN_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(unsigned), st));
     const int gx = (int)std::min<size_t>(n / FIX_TILE, GXMAX);
@@ -971,7 +973,10 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         }
         if (colLines) {
             const double* y1c = Y1;
-            void* args[] = {(void*)&y1c, (void*)&YD, (void*)&pcolArg, (void*)&xs, (void*)&ncols, (void*)&dfilt};
+            // the Gini phase's first step rides along: non-zero counts per CP_BLOCK coefficients
+            unsigned* counts = forward_only ? nullptr : pl.cnt;
+            if (counts) WN_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)Bc * (n / CP_BLOCK) * sizeof(unsigned), st));
+            void* args[] = {(void*)&y1c, (void*)&YD, (void*)&pcolArg, (void*)&xs, (void*)&ncols, (void*)&dfilt, (void*)&counts};
             WN_HIP(ctx, hipLaunchKernel(line_kernel(NP, LN_FWD_COLS, Mcol), dim3(std::min(C, LN_GX), Bc), dim3(64), args, 0, st));
         } else if ((rc = fwd_pass_big<NP>(ctx, Y1, Pcol, YD, Bc, n, cg))) {
             return rc;
@@ -983,7 +988,7 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         // the ranks; otherwise (or when the short-key ranking did not apply) they replace the coefficients in YD
         int rank_slice = 0;
         if (colLines && (rc = gini_large(ctx, YD, nullptr, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp,
-                                         pl.sort_tmp_bytes, &rank_slice)))
+                                         pl.sort_tmp_bytes, &rank_slice, true)))
             return rc;
         if (!rank_slice &&
             (rc = gini_large(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes)))

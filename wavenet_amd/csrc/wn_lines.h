@@ -158,10 +158,12 @@ struct LineGini {
 
 // ---- columns: contiguous lines of 64 M samples ---------------------------------------------------------
 // grid (workgroups per example, examples), 64 threads.  in/Y/P: chunk arrays, example stride xs, column c
-// of an example at c * 64 M.  P may be null.
+// of an example at c * 64 M.  P may be null.  counts (may be null): counts[i] receives (is added) the number
+// of non-zero coefficients among the chunk's coefficients [2048 i, 2048 (i + 1)) -- what the streamed Gini
+// phase needs first, gathered while the coefficients are still in registers.
 template <int NP, int M>
 __global__ LN_BOUNDS(64) void kc_fwd_cols(const double* __restrict__ in, double* __restrict__ Y, double* __restrict__ P, size_t xs,
-                                          int ncols, const FilterDev* filt) {
+                                          int ncols, const FilterDev* filt, unsigned* counts) {
     const int lane = threadIdx.x;
     double a[NP], b[NP];
     ln_load_taps<NP>(filt, a, b);
@@ -175,6 +177,12 @@ __global__ LN_BOUNDS(64) void kc_fwd_cols(const double* __restrict__ in, double*
         ln_forward<NP, M>(p, a, b, lane, y, small_lo);
         ln_store<M>(Y + lo, y.v, y.v[0], lane);
         if (P) ln_store<M>(P + lo, p.lo, small_lo, lane);
+        if (counts) {
+            unsigned nz = 0;
+#pragma unroll
+            for (int k = 0; k < M; k++) nz += (unsigned)__popcll(__ballot(y.v[k] != 0.0));
+            if (lane == 0) atomicAdd(&counts[lo / 2048], nz);
+        }
     }
 }
 
