@@ -339,6 +339,57 @@ __global__ __launch_bounds__(LT) void kb_bwd_level_lds(const double* __restrict_
     }
 }
 
+// ---- the levels below 4096 samples of a contiguous line in one launch ---------------------------------------
+// One workgroup runs the rest of a line's cascade (fwd_pass / bwd_pass of wn_device.h, the code of the
+// LDS-resident kernels, here on global memory: 4096 samples and their pyramid stay in the caches) instead of
+// one launch per level.  TAIL_LG: the low levels of lines longer than 2^TAIL_LG samples, and up to 8 taps whole
+// lines of up to that length (measured: at 16 and 32 taps the LDS-staged level kernels are faster for those).
+constexpr int TAIL_LG = 12, TAIL_T = 256;
+
+// in: the level's input (2^lgLen samples per line); P / out as in the level kernels.  grid (lines, examples).
+template <int NP>
+__global__ __launch_bounds__(TAIL_T) void kb_fwd_tail(const double* __restrict__ in, double* P, double* out, size_t xs, Geom g,
+                                                      int lgLen, const FilterDev* filt) {
+    double a[NP], b[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    const size_t off = (size_t)blockIdx.y * xs + (size_t)blockIdx.x * g.ls;
+    fwd_pass<NP, TAIL_T>(in + off, P + off, out + off, 1, 0, 0, lgLen, false, a, b, (int)threadIdx.x);
+}
+
+// D: errors on the coefficients of the lines, IN PLACE: on exit D[0 .. 2^lgLen) of every line holds the errors
+// on the level's input (bwd_pass).  act: that input.  grid (workgroups per example <= GXMAX, examples); a
+// workgroup walks over lines.
+template <int NP>
+__global__ __launch_bounds__(TAIL_T) void kb_bwd_tail(double* D, const double* act, const double* P, size_t xs, Geom g, int lgLen,
+                                                      const FilterDev* filt, double* partial) {
+    __shared__ double red[(TAIL_T / 64) * 2 * NP];
+    double a[NP], b[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    double gL[NP], gH[NP];
+#pragma unroll
+    for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
+    const int tid = threadIdx.x;
+    for (int line = blockIdx.x; line < (1 << g.lgNL); line += gridDim.x) {
+        const size_t off = (size_t)blockIdx.y * xs + (size_t)line * g.ls;
+        __syncthreads();
+        bwd_pass<NP, TAIL_T, (1 << TAIL_LG) / TAIL_T, true>(D + off, act + off, P + off, 1, 0, 0, lgLen, false, true, a, b, gL, gH, tid);
+    }
+#pragma unroll
+    for (int u = 0; u < NP; u++) {
+        const double sl = wave_sum(gL[u]), sh = wave_sum(gH[u]);
+        if ((tid & 63) == 0) { red[(tid >> 6) * 2 * NP + u] = sl; red[(tid >> 6) * 2 * NP + NP + u] = sh; }
+    }
+    __syncthreads();
+    if (tid < 2 * NP) {
+        double s = 0;
+#pragma unroll
+        for (int wv = 0; wv < TAIL_T / 64; wv++) s += red[wv * 2 * NP + tid];
+        partial[((size_t)blockIdx.y * GXMAX + blockIdx.x) * 2 * NP + tid] += s;
+    }
+}
+
 // Per-example gradient from the per-workgroup window sums: tap k collects gL[k] and (-1)^(N-1-k) gH[N-1-k].
 __global__ void kb_grad_finish(const double* partial, int NP, const FilterDev* filt, double* grad_e) {
     const int ex = blockIdx.x, kp = threadIdx.x;
@@ -709,7 +760,9 @@ int fwd_pass_big(wn_context* ctx, const double* in, double* P, double* out, int 
         WN_HIP(ctx, hipMemsetAsync(P, 0, (size_t)B * n * sizeof(double), st));
         return WN_OK;
     }
-    for (int i = g.lgLen - 1; i >= 0; i--) {
+    // contiguous lines: the levels below 2^TAIL_LG samples in one launch
+    const int tail = (g.es == 1 && !g.lanesOnLines && ctx->wave64 && (g.lgLen > TAIL_LG || NP <= 8)) ? std::min(g.lgLen, TAIL_LG) : 0;
+    for (int i = g.lgLen - 1; i >= tail; i--) {
         const double* src = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i) * g.es;
         if (NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && (1 << i) >= LT) {
             hipLaunchKernelGGL(kb_fwd_level_lds<NP>, dim3((1u << (g.lgNL + i)) / LT, B), dim3(LT), 0, st, src,
@@ -719,7 +772,12 @@ int fwd_pass_big(wn_context* ctx, const double* in, double* P, double* out, int 
         hipLaunchKernelGGL(kb_fwd_level<NP>, grid_for(1 << (g.lgNL + i), B), dim3(BT), 0, st, src,
                            P + (size_t)(1 << i) * g.es, out + (size_t)(1 << i) * g.es, n, g, i, ctx->dfilt);
     }
-    hipLaunchKernelGGL(kb_finish_pass, grid_for(1 << g.lgNL, B), dim3(BT), 0, st, out, P, n, g);
+    if (tail) {
+        const double* src = (tail == g.lgLen) ? in : P + ((size_t)1 << tail);
+        hipLaunchKernelGGL(kb_fwd_tail<NP>, dim3(1u << g.lgNL, B), dim3(TAIL_T), 0, st, src, P, out, n, g, tail, ctx->dfilt);
+    } else {
+        hipLaunchKernelGGL(kb_finish_pass, grid_for(1 << g.lgNL, B), dim3(BT), 0, st, out, P, n, g);
+    }
     WN_HIP(ctx, hipGetLastError());
     return WN_OK;
 }
@@ -729,11 +787,22 @@ int fwd_pass_big(wn_context* ctx, const double* in, double* P, double* out, int 
 // holding the errors on the input afterwards.  partial may be null (inverse transform: no gradient).
 template <int NP>
 int bwd_pass_big(wn_context* ctx, const double* coef, const double* in, const double* P, double* pingA,
-                 double* pingB, int B, size_t n, Geom g, bool lastPropagate, double* partial, const double** result) {
+                 double* pingB, int B, size_t n, Geom g, bool lastPropagate, double* partial, const double** result,
+                 double* coefScratch = nullptr) {
     hipStream_t st = ctx->stream;
     const double* lp = coef;
     double* dst = pingA;
-    for (int i = 0; i < g.lgLen; i++) {
+    // coefScratch: coef again, writable (the caller does not need the errors afterwards).  Contiguous lines
+    // then have their levels below 2^TAIL_LG samples done in place by one launch; when that is the whole
+    // pass, its result -- the errors on the lines -- is in coef.
+    int first = 0;
+    if (coefScratch && partial && g.es == 1 && !g.lanesOnLines && ctx->wave64 && (g.lgLen > TAIL_LG || (NP <= 8 && lastPropagate))) {
+        first = std::min(g.lgLen, TAIL_LG);
+        const double* act = (first == g.lgLen) ? in : P + ((size_t)1 << first);
+        hipLaunchKernelGGL(kb_bwd_tail<NP>, dim3(std::min(1 << g.lgNL, GXMAX), B), dim3(TAIL_T), 0, st, coefScratch, act, P, n, g, first,
+                           ctx->dfilt, partial);
+    }
+    for (int i = first; i < g.lgLen; i++) {
         const double* hp = coef + (size_t)(1 << i) * g.es;
         const bool propagate = (i != g.lgLen - 1 || lastPropagate);
         if (partial && NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && (1 << i) >= LT) {
@@ -1006,7 +1075,7 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
             WN_HIP(ctx, hipLaunchKernel(line_kernel(NP, rank_slice ? LN_BWD_COLS_RANKS : LN_BWD_COLS, Mcol), dim3(std::min(C, LN_GX), Bc),
                                         dim3(64), args, 0, st));
             D1 = pl.A;
-        } else if ((rc = bwd_pass_big<NP>(ctx, YD, Y1, Pcol, pl.A, pl.Bb, Bc, n, cg, lgC > 0, pl.partial, &D1))) {
+        } else if ((rc = bwd_pass_big<NP>(ctx, YD, Y1, Pcol, pl.A, pl.Bb, Bc, n, cg, lgC > 0, pl.partial, &D1, Yout ? nullptr : YD))) {
             return rc;
         }
         if (lgC > 0) {
