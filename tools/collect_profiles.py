@@ -1,5 +1,5 @@
-"""Copies the summaries of tools/measure_round.sh from gpurun_out/measure/ into profiles/ (named per
-round) and recomputes profiles/traffic.json: HBM-side bytes per launch of the training kernel from the
+"""Copies the summaries of tools/measure_round.sh from gpurun_out/measure/ into profiles/ (file names
+prefixed with the tag given) and recomputes profiles/traffic.json: HBM-side bytes per launch of the training kernel from the
 FETCH_SIZE and WRITE_SIZE passes (the counters are in KB; raw figures, see the comment in the file).
 
     python tools/collect_profiles.py r01

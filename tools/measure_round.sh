@@ -1,5 +1,5 @@
 #!/bin/bash
-# The round's measurement on the GPU box: default bench (with the CPU baseline), the same command under
+# The full measurement on the GPU box: default bench (with the CPU baseline), the same command under
 # rocprofv3 --kernel-trace --stats, and the PMC passes (one counter group per run).  Results land in
 # gpurun_out/measure/; tools/collect_profiles.py copies the summaries into profiles/.
 #   tools/measure_round.sh        (from the repository root, on the GPU box)
