@@ -341,3 +341,21 @@ def test_drift_over_updates(R, C, N):
     assert rep["max_one_step_relative_error"] < 1e-9, rep
     drift = rep["free_running_relative_drift_after_updates"]
     assert drift["10"] < 1e-9 and drift["100"] < 1e-8, rep
+
+
+@pytest.mark.parametrize("R,C,N,B", [(64, 64, 4, 300), (1024, 1, 16, 300), (32, 32, 8, 500), (512, 512, 4, 6), (8192, 1, 32, 5)])
+def test_results_are_reproducible_bit_for_bit(ctx, R, C, N, B):
+    """No floating-point atomics anywhere: the same batch gives the same sums, gradients and costs, bit for
+    bit, run after run (partial sums are combined in a fixed order)."""
+    X = make_inputs(B, R, C, seed=R + N, sparse=True)
+    dX = to_dev(X)
+    ctx.set_filter(filt_for(N, 9))
+    outs = []
+    for _ in range(3):
+        dG, dS = dev_empty(B * N), dev_empty(B)
+        ctx.train_batch(dX, B, R, C, dG, dS)
+        outs.append((ctx.sums().copy(), dG.cpu().numpy().copy(), dS.cpu().numpy().copy()))
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0])
+        assert np.array_equal(o[1], outs[0][1])
+        assert np.array_equal(o[2], outs[0][2])
