@@ -145,3 +145,32 @@ def test_no_per_example_outputs(ctx, oracle):
     og, os_, _ = oracle.band_train_batch(a, X)
     assert relerr(sums[:4], og) < 1e-10
     assert sums[4] == pytest.approx(os_, rel=1e-12)
+
+
+@pytest.mark.parametrize("n", [256, 512])
+@pytest.mark.parametrize("N", [2, 4, 6, 8])
+def test_shorter_signals_against_oracle_and_block_kernel(ctx, ctx_block, oracle, n, N):
+    """Signals of 256 and 512 samples with up to 8 taps take the one-wave kernel built from the line
+    pieces (k_train_line): against the oracle, and example by example against the workgroup kernel on
+    sparse inputs with exact ties."""
+    B = 70
+    a = filt_for(N, 3)
+    rng = np.random.default_rng(n + N)
+    X = np.where(rng.random((B, n, 1)) < 0.8, 0.0, rng.random((B, n, 1)))
+    X[:, 0, 0] += 0.25
+    X[3] = np.round(X[3] * 4) / 4          # few distinct values: ties
+    def go(c):
+        c.set_filter(a)
+        dG, dS = dev_empty(B * N), dev_empty(B)
+        c.train_batch(to_dev(X), B, n, 1, dG, dS)
+        return dG.cpu().numpy().reshape(B, N), dS.cpu().numpy(), c.sums()
+    G, S, sums = go(ctx)
+    Gb, Sb, sumsb = go(ctx_block)
+    assert sums[N + 1] == 0
+    assert np.abs(S - Sb).max() < 1e-13 and relerr(G, Gb) < 1e-11 and relerr(sums, sumsb) < 1e-11
+    og, os_, bad = oracle.band_train_batch(a, X)
+    assert bad == 0
+    assert sums[N] == pytest.approx(os_, rel=1e-12)
+    for e in (0, 1, 2):
+        ge, se, _ = oracle.band_train_batch(a, X[e:e + 1])
+        assert relerr(G[e], ge) < 1e-10 and S[e] == pytest.approx(se, rel=1e-12)

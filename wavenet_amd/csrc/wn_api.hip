@@ -30,6 +30,7 @@ extern "C" const void* wn_kernel_wave64(int np);
 extern "C" const void* wn_kernel_wave64_transform(int kind, int np);
 extern "C" const void* wn_kernel_wave64_sparse();
 extern "C" const void* wn_kernel_wave1d(int np);
+extern "C" const void* wn_kernel_wave1d_line(int np, int M);
 extern "C" const void* wn_kernel_sparse(int sc);
 
 namespace {
@@ -658,6 +659,9 @@ int wn_train_batch(wn_context* ctx, const double* X, int B, int R, int C, double
             // one wave per example, four examples per workgroup; one partial-sum slot per wave
             rc = launch(ctx, wave64, 256, (size_t)4 * wn::W64_TILE * sizeof(double), (B + 3) / 4, A, &grid);
             grid *= 4;
+        } else if ((lgR == 8 || lgR == 9) && lgC == 0 && ctx->NP <= 8 && ctx->wave64) {
+            // 1D signals of 256 and 512 samples, up to 8 taps: one wave per example, cascade in registers
+            rc = launch(ctx, wn_kernel_wave1d_line(ctx->NP, 1 << (lgR - 6)), 64, (size_t)(512 + 8) * sizeof(double), B, A, &grid);
         } else if (lgR == 10 && lgC == 0 && ctx->wave64) {
             // 1D signals of 1024 samples: one wave per example, one example in flight per workgroup
             rc = launch(ctx, wn_kernel_wave1d(ctx->NP), 64, (size_t)(1024 + 8) * sizeof(double), B, A, &grid);

@@ -389,4 +389,69 @@ __global__ LN_BOUNDS(256) void kr_grad_rows(const double* __restrict__ coef, con
     }
 }
 
+// ---- training step of 1D signals of 256 or 512 samples (128 works too) ---------------------------------------------------
+// One wave per example as k_train1d1024 (wn_wave1d.h), from the line pieces above: cascade in registers,
+// the coefficients through LDS for the Gini phase (gini_phase of the workgroup-per-example kernels, run by one
+// wave; Q = log2 of the sort slots per lane), backward from the errors in the same lane layout.
+template <int NP, int M>
+__global__ __launch_bounds__(64, 2) void k_train_line(FusedArgs A) {
+    constexpr int n = 64 * M;
+    constexpr int Q = (M == 2) ? 1 : 3;              // sort slots per lane: 2 (128 samples) or 8 (256, 512)
+    constexpr int SLOTS = 64 << Q;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* bufY = smem;                             // coefficients / sort slots / errors
+    double* red = bufY + SLOTS;
+    int* flag = reinterpret_cast<int*>(red + 4);
+    const int lane = threadIdx.x;
+    const FilterDev* filt = A.filt;
+    double a[NP], b[NP];
+    ln_load_taps<NP>(filt, a, b);
+    const int N = filt->N, dpad = filt->d;
+    double accG = 0, accS = 0, accBad = 0;
+    for (int e = blockIdx.x; e < A.B; e += gridDim.x) {
+        LinePyramid<M> p;
+        LineLane<M> y;
+        double unused_lo;
+        ln_load_samples<M>(A.X + (size_t)e * n, p.x, lane);
+        ln_forward<NP, M>(p, a, b, lane, y, unused_lo);
+        __syncthreads();                             // the previous example's errors have been read
+        ln_store<M>(bufY, y.v, y.v[0], lane);
+        __syncthreads();
+        const double S = gini_phase<64, Q, true>(bufY, n, red, flag, lane);
+        LineLane<M> dy;
+        ln_load<M>(bufY, dy, lane);
+        double gL[NP], gH[NP], dtop[M];
+#pragma unroll
+        for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
+        ln_backward<NP, M, false>(p, dy, dtop, a, b, gL, gH, lane);
+        // tap k' collects gL[k'] and sH[k'] gH[NP-1-k'], summed over the 64 lanes
+        double mine = 0;
+#pragma unroll
+        for (int kp = 0; kp < NP; kp++) {
+            double c = filt->vL[kp] * gL[kp] + filt->sH[kp] * gH[NP - 1 - kp];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+            if (lane == kp) mine = c;
+        }
+        const int k = lane - dpad;
+        if (lane < NP && k >= 0 && k < N) {
+            accG += mine;
+            if (!isfinite(mine)) accBad += 1;
+            if (A.grad) A.grad[(size_t)e * N + k] = mine;
+        }
+        if (lane == 0) {
+            accS += S;
+            if (!isfinite(S)) accBad += 1;
+            if (A.S) A.S[e] = S;
+        }
+    }
+    double bad = accBad;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, 64);
+    double* part = A.partial + (size_t)blockIdx.x * PSTRIDE;
+    const int k = lane - dpad;
+    if (lane < NP && k >= 0 && k < N) part[k] = accG;
+    if (lane == 0) { part[N] = accS; part[N + 1] = bad; }
+}
+
 }  // namespace wn

@@ -41,3 +41,20 @@ extern "C" const void* wn_kernel_wave1d(int np) {
     }
     return nullptr;
 }
+
+// training kernels of 1D signals of 128, 256 and 512 samples, one wave per example (k_train_line, wn_lines.h)
+extern "C" const void* wn_kernel_wave1d_line_np2(int M);
+extern "C" const void* wn_kernel_wave1d_line_np4(int M);
+extern "C" const void* wn_kernel_wave1d_line_np8(int M);
+extern "C" const void* wn_kernel_wave1d_line_np16(int M);
+extern "C" const void* wn_kernel_wave1d_line_np32(int M);
+extern "C" const void* wn_kernel_wave1d_line(int np, int M) {
+    switch (np) {
+        case 2: return wn_kernel_wave1d_line_np2(M);
+        case 4: return wn_kernel_wave1d_line_np4(M);
+        case 8: return wn_kernel_wave1d_line_np8(M);
+        case 16: return wn_kernel_wave1d_line_np16(M);
+        case 32: return wn_kernel_wave1d_line_np32(M);
+    }
+    return nullptr;
+}
