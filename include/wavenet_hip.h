@@ -44,7 +44,7 @@ enum {
     WN_ERR_HIP = 5,          /* a HIP runtime call failed                                       */
     WN_ERR_COMM = 6,         /* an RCCL call failed                                             */
     WN_ERR_NONFINITE = 7,    /* NaN/Inf in cost or gradient ("diverging solution",
-                                src/Wavenet.cxx:234-241)                                        */
+                                src/Wavenet.cxx:234-241): returned by wn_num_updates            */
     WN_ERR_STATE = 8         /* call order: no filter set, no communicator, ...                 */
 };
 
@@ -84,7 +84,8 @@ int wn_memcpy_d2h(wn_context* ctx, void* dst_host, const void* src_dev, size_t b
  * (Wavenet::cacheOperators_, src/Wavenet.cxx:767-786) and the weight matrices of
  * Wavenet::cacheWeights_ (src/Wavenet.cxx:800-839).  No matrix is built: the N taps and the
  * derived high-pass taps b_i = (-1)^i a_{N-1-i} (src/HighpassOperator.cxx:16-18) are stored on
- * the device for the kernels.  Resets the momentum when N changes, keeps it otherwise.
+ * the device for the kernels.  Resets the momentum when N changes, keeps it otherwise; takes the
+ * non-finite flag (wn_apply_update) down.
  */
 int wn_set_filter(wn_context* ctx, const double* a_host, int N);
 int wn_get_filter(wn_context* ctx, double* a_host, int* N);        /* synchronises */
@@ -167,12 +168,18 @@ int wn_set_sums_buffer(wn_context* ctx, double* sums_dev);
  * Coach's annealing changes it per event, src/Coach.cxx:176-180); inertia_eff is the caller's
  * evaluation of src/Wavenet.cxx:757.  The new filter and the cost are appended to device-side
  * logs (Wavenet::filterLog / costLog).
+ * A batch whose sums are not finite is NOT applied, as the reference's train() fails before it
+ * queues anything (src/Wavenet.cxx:234-241): filter, momentum and logs stay as they were, every
+ * later wn_apply_update is skipped too, and wn_num_updates reports WN_ERR_NONFINITE until
+ * wn_set_filter or wn_clear_logs.  The call itself is asynchronous and returns WN_OK.
  */
 int wn_apply_update(wn_context* ctx, double batch_total, double lambda_sum, double alpha,
                     double inertia_eff, int do_wavelet);
 
-/* Number of updates applied since the last wn_set_filter / wn_clear_logs. */
-int wn_num_updates(wn_context* ctx, int* steps);  /* synchronises */
+/* Number of updates applied since the context was created or wn_clear_logs (wn_set_filter does not
+ * reset it).  Returns WN_ERR_NONFINITE (with *steps filled in) once a batch was rejected for
+ * non-finite sums.  Synchronises. */
+int wn_num_updates(wn_context* ctx, int* steps);
 /*
  * Copies log entries [first, first+count): filters_host[count][N] are the filters after each
  * update, costs_host[count] the batch-mean costs.  Either may be NULL.  Synchronises.

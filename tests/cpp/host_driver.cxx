@@ -102,13 +102,16 @@ int main(int argc, char** argv) {
     if (mode == "train") {
         const unsigned R = std::atoi(argv[2]), C = std::atoi(argv[3]), N = std::atoi(argv[4]), E = std::atoi(argv[5]);
         const unsigned batch = std::atoi(argv[6]);
-        const double inertia = std::atof(argv[7]);
+        const double inertia = std::atof(argv[7]);   // "inertia" or "inertia:timescale"
+        const char* colon = std::strchr(argv[7], ':');
+        const double timeScale = colon ? std::atof(colon + 1) : 0.;
         const bool batched = std::atoi(argv[8]) != 0;
         std::vector<double> in = readAll(argv[9]);
         const size_t n = (size_t)R * C;
         Wavenet w(10.0, 1e-3);
         w.setBatchSize(batch);
         if (inertia > 0) w.setInertia(inertia);
+        if (timeScale > 0) w.setInertiaTimeScale(timeScale);
         if (!w.setFilter(Col(N, in.data()))) return 3;
         if (batched) {
             // an odd split exercises the pending-queue path between device rounds
@@ -206,12 +209,16 @@ int main(int argc, char** argv) {
         coach.setUseAdaptiveBatchSize((flags >> 1) & 1u);
         coach.setUseSimulatedAnnealing((flags >> 2) & 1u);
         if (target > 0) coach.setTargetPrecision(target);
+        if (const char* inits = std::getenv("WAVENET_TEST_NUM_INITS")) coach.setNumInits(std::atoi(inits));
+        if (const char* al = std::getenv("WAVENET_TEST_ALPHA")) w.setAlpha(std::atof(al));
         if (std::getenv("WAVENET_TEST_HOST_GENERATE")) coach.setGenerateOnDevice(false);
         if (const char* dir = std::getenv("WAVENET_TEST_SNAPSHOT_DIR")) {   // relative directory for the snapshots
             coach.setBasedir(dir);
             coach.setSaveSnapshots();
         }
         if (!coach.run()) return 4;
+        double updates = (double)w.costLog().size();
+        dump("updates", &updates, 1);
         dumpLogs(w);
         if (coach.saveSnapshots()) {   // what the snapshot of initialisation 0 holds
             Wavenet v;

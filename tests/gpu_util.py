@@ -20,6 +20,10 @@ def dev_empty(n):
 
 
 def relerr(a, b):
+    """Largest element-wise relative error of a against b, with an absolute floor of 1e-4 of b's
+    largest magnitude: relerr(a, b) <= t  <=>  |a - b| <= t |b| + 1e-4 t max|b| for every element.
+    At t = 1e-9 that is the stated tolerance on coefficients and activations, with 1e-13 max|b| of
+    slack for entries that are small only by cancellation."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     scale = max(np.abs(b).max(), 1e-300)
-    return np.abs(a - b).max() / scale
+    return (np.abs(a - b) / (np.abs(b) + 1e-4 * scale)).max()

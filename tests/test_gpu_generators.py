@@ -76,3 +76,30 @@ def test_generated_batch_trains_like_an_uploaded_one(ctx):
     s1 = ctx.sums().copy()
     ctx.train_batch(to_dev(G.calorimeter(B, R, C, seed=5)), B, R, C)
     assert np.array_equal(ctx.sums(), s1)
+
+
+def test_calorimeter_tables_survive_a_cost_grid():
+    """One context: calorimeter batch, a cost grid large enough to (re)allocate the filter table, the
+    same batch again, then a larger grid (the table grows) and the batch a third time -- bit-identical
+    every time, and the context closes cleanly."""
+    import torch
+    from wavenet_amd import Context, generators as G
+    import filters as F
+    c = Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    B, R, C = 9, 64, 64
+    ref = G.calorimeter(B, R, C, seed=77)
+    d = dev_empty(B * R * C)
+    S = dev_empty(600 * B)
+    rng = np.random.default_rng(3)
+    for nfilters in (40, 600):
+        c.generate_calorimeter(d, B, R, C, seed=77)
+        torch.cuda.synchronize()
+        assert np.array_equal(from_dev(d, B, R, C), ref)
+        filters = np.asarray(F.DB4)[None, :] * (1 + 1e-2 * rng.standard_normal((nfilters, 4)))
+        c.sparse_cost_grid(d, B, R, C, filters, S)
+        torch.cuda.synchronize()
+        assert np.isfinite(S[:nfilters * B].cpu().numpy()).all()
+    c.generate_calorimeter(d, B, R, C, seed=77)
+    torch.cuda.synchronize()
+    assert np.array_equal(from_dev(d, B, R, C), ref)
+    c.close()

@@ -72,7 +72,7 @@ def test_sparse_term_and_deriv(ctx, oracle, n):
     S = dS.cpu().numpy()
     for e in range(B):
         assert S[e] == pytest.approx(oracle.sparse_term(Y[e]), rel=1e-11)
-        assert relerr(D[e], oracle.sparse_term_deriv(Y[e])) < 1e-10
+        assert relerr(D[e], oracle.sparse_term_deriv(Y[e])) < 1e-9
     onehot = np.zeros((1, n))
     onehot[0, n // 3] = 2.0
     ctx.sparse_term(torch.from_numpy(onehot.reshape(-1)).cuda(), 1, n, dS)
@@ -177,7 +177,7 @@ def test_sparse_term_32bit_keys_against_64bit_sort(ctx, oracle, n, B):
         exact.close()
     assert np.abs(S - S2).max() < 1e-13
     for e in range(B):
-        assert relerr(D[e], D2[e]) < 1e-12
+        assert relerr(D[e], D2[e]) < 1e-11
         assert S[e] == pytest.approx(oracle.sparse_term(Y[e]), rel=1e-11)
         assert relerr(D[e], oracle.sparse_term_deriv(Y[e])) < 1e-10
 
@@ -208,7 +208,7 @@ def test_sparse_term_zeros_left_out_of_the_sort(ctx, oracle, n, in_place):
     for e in range(1, B):
         assert S[e] == pytest.approx(oracle.sparse_term(Y[e]), rel=1e-11)
         want = oracle.sparse_term_deriv(Y[e])
-        assert relerr(D[e], want) < 1e-10
+        assert relerr(D[e], want) < 1e-9
         assert np.all(D[e][Y[e] == 0] == 0)
     assert S[3] == pytest.approx(1.0 / n, rel=1e-12)
 

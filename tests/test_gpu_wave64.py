@@ -100,7 +100,7 @@ def test_many_passes_against_block_kernel(ctx, ctx_block, N):
     Gb, Sb, sumsb = run(ctx_block, a, X)
     assert sums[N + 1] == 0 and sumsb[N + 1] == 0
     assert np.abs(S - Sb).max() < 1e-13
-    assert relerr(G, Gb) < 1e-11
+    assert relerr(G, Gb) < 1e-10
     assert relerr(sums, sumsb) < 1e-11
 
 
@@ -127,6 +127,30 @@ def test_exact_ties_and_zeros(ctx, ctx_block, oracle):
     for e in range(B):
         _, se, _ = oracle.band_train_batch(a, X[e:e + 1])
         assert S[e] == pytest.approx(se, rel=1e-10)
+
+
+@pytest.mark.parametrize("taps", [(0.5, 0.5), (0.5, 0.25, 0.5, -0.25), (0.75, 0.5, 0.25, -0.5, 1.0, 0.125, -0.25, 0.5)])
+@pytest.mark.parametrize("wave64", [True, False])
+def test_exact_ties_against_oracle(ctx, ctx_block, oracle, taps, wave64):
+    """Tie handling checked against the oracle itself: with dyadic taps and small-integer inputs every
+    product and sum on the path is exact, fused or not, so equal magnitudes are equal in both
+    evaluations, no rank can flip, and the gradient must agree with the oracle's (ties in ascending
+    index order in both)."""
+    a = np.array(taps)
+    B = 5
+    rng = np.random.default_rng(len(taps))
+    X = np.zeros((B, R, C))
+    for e in range(B):
+        for _ in range(3 + 4 * e):
+            X[e, rng.integers(R), rng.integers(C)] = float(rng.integers(1, 5))
+    X[B - 1, 8:40, 16:32] = 2.0
+    c = ctx if wave64 else ctx_block
+    G, S, sums = run(c, a, X)
+    assert sums[len(a) + 1] == 0
+    for e in range(B):
+        ge, se, _ = oracle.band_train_batch(a, X[e:e + 1])
+        assert relerr(G[e], ge) < 1e-10
+        assert S[e] == pytest.approx(se, rel=1e-12)
 
 
 def test_near_ties_take_exact_path(ctx, ctx_block, oracle):

@@ -91,16 +91,21 @@ def test_wavenet_methods(oracle, R, C, N):
 
 
 @pytest.mark.parametrize("batched", [0, 1])
-@pytest.mark.parametrize("R,C,N,E,batch,inertia", [(16, 16, 4, 50, 8, 0.0), (32, 1, 2, 40, 1, 0.5), (8, 8, 16, 45, 10, 0.9)])
-def test_train_matches_oracle(oracle, R, C, N, E, batch, inertia, batched):
+@pytest.mark.parametrize("R,C,N,E,batch,inertia,tau", [(16, 16, 4, 50, 8, 0.0, 0), (32, 1, 2, 40, 1, 0.5, 0), (8, 8, 16, 45, 10, 0.9, 0),
+                                                        (16, 16, 4, 60, 4, 0.9, 5.0), (32, 1, 2, 40, 1, 0.5, 2.5)])
+def test_train_matches_oracle(oracle, R, C, N, E, batch, inertia, tau, batched):
+    """tau > 0: the inertia is switched on gradually, inertia * (1 - exp(-float(steps) / tau))
+    (src/Wavenet.cxx:756-757), in the queue path and in the batches-on-the-device path alike."""
     rng = np.random.default_rng(E + N)
     a = F.perturbed(F.daubechies(N), 1e-2, 2)
     X = rng.random((E, R, C))
     flat = np.concatenate([colmajor(x) for x in X])
-    out, _ = run_driver(["train", R, C, N, E, batch, inertia, batched], [a, flat])
+    out, _ = run_driver(["train", R, C, N, E, batch, f"{inertia}:{tau}" if tau else inertia, batched], [a, flat])
     w = oracle.Wavenet(lam=10.0, alpha=1e-3)
     w.set_batch_size(batch)
     w.set_inertia(inertia)
+    if tau:
+        w.set_inertia_time_scale(tau)
     w.set_filter(a)
     for x in X:
         w.train(x)
@@ -109,15 +114,22 @@ def test_train_matches_oracle(oracle, R, C, N, E, batch, inertia, batched):
     assert np.allclose(out["momentum"], w.momentum(), rtol=1e-8, atol=1e-15)
 
 
+@pytest.mark.parametrize("inits", [1, 3])
 @pytest.mark.parametrize("flags,events,epochs,batch,target", [(0, 64, 1, 8, -1), (4, 60, 2, 4, -1), (3, 400, 1, 2, -1),
-                                                              (1, 600, 1, 2, 5e-5)])
-def test_coach_run_matches_oracle(oracle, flags, events, epochs, batch, target):
+                                                              (1, 600, 1, 2, 5e-5), (3, 480, 1, 4, -1), (2, 300, 1, 3, -1),
+                                                              (1, 330, 1, 3, -1)])
+def test_coach_run_matches_oracle(oracle, flags, events, epochs, batch, target, inits):
     """Coach::run with the deterministic UniformGenerator against the oracle's event loop: fixed schedule,
-    simulated annealing over two epochs, adaptive learning rate + batch size, and early stop."""
+    simulated annealing over two epochs, adaptive learning rate + batch size (batches of 2, 3 and 4: the
+    first adaptation falls on the update the reference's per-event bookkeeping puts it on), and early
+    stop.  With several initialisations (src/Coach.cxx:130-144) every one starts from the restored
+    learning rate, batch size and lambda and from the given initial filter, so the last one must equal
+    the oracle's single run."""
     from wavenet_amd import generators as G
     R, C, N, seed = 8, 8, 4, 42
     a = F.perturbed(F.DB4, 5e-2, 5)
-    out, _ = run_driver(["coach", R, C, N, events, epochs, batch, flags, seed, target], [a])
+    out, _ = run_driver(["coach", R, C, N, events, epochs, batch, flags, seed, target], [a],
+                        env={"WAVENET_TEST_NUM_INITS": str(inits)})
     X = G.uniform(events, R, C, seed=seed)   # the C++ generator hashes (seed, event, pixel) identically
     w = oracle.Wavenet(lam=10.0, alpha=1e-3)
     w.set_batch_size(batch)
@@ -130,6 +142,20 @@ def test_coach_run_matches_oracle(oracle, flags, events, epochs, batch, target):
     assert np.allclose(out["costLog"], ocl, rtol=1e-9, atol=1e-15)
     lam, alpha, bs = out["misc"]
     assert lam == pytest.approx(w.lam(), rel=1e-14) and alpha == w.alpha() and bs == w.batch_size()
+
+
+def test_coach_stops_on_a_diverging_solution():
+    """A learning rate far too large drives the filter to infinity within a few updates.  The reference's
+    train() then returns false and Coach::run ends the initialisation (src/Wavenet.cxx:234-241,
+    src/Coach.cxx:186-189); here the update kernel rejects the batch whose sums are not finite, the host
+    layer sees it at its next look at the device and run() stops: far fewer updates than events / batch,
+    every logged filter and cost finite."""
+    R, C, N, seed = 16, 16, 4, 11
+    a = F.perturbed(F.DB4, 5e-2, 5)
+    out, err = run_driver(["coach", R, C, N, 4000, 1, 4, 0, seed, -1], [a], env={"WAVENET_TEST_ALPHA": "1e6"})
+    assert "diverging solution" in err
+    assert out["updates"][0] < 200
+    assert np.isfinite(out["filterLog"]).all() and np.isfinite(out["costLog"]).all() and np.isfinite(out["filter"]).all()
 
 
 def test_coach_generates_on_the_device_or_on_the_host_alike():

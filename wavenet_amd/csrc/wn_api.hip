@@ -95,7 +95,7 @@ int check_shape(wn_context* ctx, int B, int R, int C, bool need_filter, int* lgR
     return WN_OK;
 }
 
-int launch(wn_context* ctx, const void* func, int T, size_t shmem, int B, wn::FusedArgs& A, int* grid_out) {
+int launch(wn_context* ctx, const void* func, int T, size_t shmem, int B, wn::FusedArgs& A, int* grid_out, int grid_cap = 1 << 30) {
     if (!func) return fail(ctx, WN_ERR_UNSUPPORTED, "no kernel compiled for this configuration");
     auto it = ctx->lds_configured.find(func);
     if (it == ctx->lds_configured.end() || it->second < shmem) {
@@ -115,6 +115,7 @@ int launch(wn_context* ctx, const void* func, int T, size_t shmem, int B, wn::Fu
     }
     long long grid = (long long)perCU * ctx->numCU;
     if (grid > B) grid = B;
+    if (grid > grid_cap) grid = grid_cap;   // the kernels stride over the batch: fewer workgroups only take more turns
     if (grid < 1) grid = 1;
     if (grid_out) *grid_out = (int)grid;
     void* args[] = {&A};
@@ -154,9 +155,17 @@ __global__ __launch_bounds__(64) void k_update(wn::FilterDev* f, const double* s
                                                double* logC, int cap) {
     __shared__ double a[wn::MAXTAPS], b[wn::MAXTAPS], prefA[wn::MAXTAPS + 1], prefB[wn::MAXTAPS + 1];
     __shared__ float devA[wn::MAXTAPS + 1], devB[wn::MAXTAPS + 1];
-    __shared__ double anew[wn::MAXTAPS];
+    __shared__ double anew[wn::MAXTAPS], pnew[wn::MAXTAPS], cost;
     const int t = threadIdx.x;
     const int N = f->N;
+    // A batch whose sums are not finite is not applied (the reference's train() fails before anything is
+    // queued, src/Wavenet.cxx:234-241), and neither is any batch after it: the flag stays up until
+    // wn_set_filter / wn_clear_logs.
+    const bool bad_here = (t <= N && !isfinite(sums[t])) || (t == N + 1 && sums[t] != 0.0);
+    if (__any(bad_here) || f->nonfinite) {
+        if (t == 0) f->nonfinite = 1;
+        return;
+    }
     if (t < N) a[t] = f->a_true[t];
     __syncthreads();
     if (t < N) b[t] = wn::parity_sign(t) * a[N - t - 1];
@@ -182,10 +191,9 @@ __global__ __launch_bounds__(64) void k_update(wn::FilterDev* f, const double* s
         gbar /= Bf;                                   // gradient /= float(size)          :727
         double p = f->momentum[t] * inertia_eff;      // scaleMomentum_                    :760
         p += -alpha * gbar;                           // addMomentum_                      :761
-        f->momentum[t] = p;
+        pnew[t] = p;
         anew[t] = a[t] + p;                           // setFilter(m_filter + m_momentum)  :762
     }
-    __syncthreads();
     if (t == 0) {
         double reg = 0.;                                                            // RegTerm
         float R2 = 0.f;
@@ -200,8 +208,18 @@ __global__ __launch_bounds__(64) void k_update(wn::FilterDev* f, const double* s
             reg += sumb * sumb;
         }
         reg = reg / 2.;
+        cost = (sums[N] + lambda_sum * reg) / Bf;                                   // :227, :733
+    }
+    __syncthreads();
+    // the same for a filter or a cost that overflowed on the way
+    if (__any(t < N && !isfinite(anew[t])) || !isfinite(cost)) {
+        if (t == 0) f->nonfinite = 1;
+        return;
+    }
+    if (t < N) f->momentum[t] = pnew[t];
+    if (t == 0) {
         const int idx = f->steps % cap;
-        logC[idx] = (sums[N] + lambda_sum * reg) / Bf;                              // :227, :733
+        logC[idx] = cost;
         f->steps = f->steps + 1;
         for (int k = 0; k < wn::MAXTAPS; k++) logF[(size_t)idx * wn::MAXTAPS + k] = (k < N) ? anew[k] : 0.0;
         write_padded_filter(f, anew);
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(64) void k_update(wn::FilterDev* f, const double* s
 }
 
 __global__ void k_reset_steps(wn::FilterDev* f) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) f->steps = 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { f->steps = 0; f->nonfinite = 0; }
 }
 
 // ---- RCCL through dlopen: the library is only needed by multi-GPU callers ----------------------
@@ -387,6 +405,7 @@ int wn_set_filter(wn_context* ctx, const double* a, int N) {
     if (!ctx->has_filter || ctx->N != N) {
         WN_HIP(ctx, hipMemsetAsync(ctx->dfilt->momentum, 0, sizeof(h.momentum), ctx->stream));  // :31-33
     }
+    WN_HIP(ctx, hipMemsetAsync(&ctx->dfilt->nonfinite, 0, sizeof(int), ctx->stream));
     WN_HIP(ctx, hipStreamSynchronize(ctx->stream));  // h is a stack object
     ctx->has_filter = true;
     ctx->N = N;
@@ -560,8 +579,7 @@ int wn_sparse_cost_grid(wn_context* ctx, const double* X, int B, int R, int C, c
     const int chunk = F < 4096 ? F : 4096;
     if (ctx->grid_filters_cap < chunk) {
         WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->gen_tables) (void)hipFree(ctx->gen_tables);
-    if (ctx->grid_filters) (void)hipFree(ctx->grid_filters);
+        if (ctx->grid_filters) (void)hipFree(ctx->grid_filters);
         ctx->grid_filters = nullptr;
         ctx->grid_filters_cap = 0;
         WN_HIP(ctx, hipMalloc((void**)&ctx->grid_filters, (size_t)chunk * sizeof(wn::FilterDev)));
@@ -628,6 +646,47 @@ int wn_sparse_cost_grid(wn_context* ctx, const double* X, int B, int R, int C, c
 
 // ---- training ---------------------------------------------------------------------------------------
 
+// The LDS-resident and one-wave-per-example training kernels plus the batch reduction: per-workgroup (per-wave)
+// sums go to `partial` (room for max_slots slots), the N + 2 sums to `sums`.
+static int train_fused(wn_context* ctx, const double* X, int B, int lgR, int lgC, int sc, double* grad, double* Sout,
+                       double* partial, int max_slots, double* sums) {
+    const int R = 1 << lgR, C = 1 << lgC;
+    const SizeClass& S = kSizeClasses[sc < 0 ? 0 : sc];
+    wn::FusedArgs A;
+    memset(&A, 0, sizeof(A));
+    A.B = B; A.lgR = lgR; A.lgC = lgC; A.filt = ctx->dfilt;
+    A.X = X; A.grad = grad; A.S = Sout; A.partial = partial;
+    int grid = 0, rc = WN_OK;
+    if (B > 0) {
+        const bool prof = ctx->prof_used < (int)ctx->prof_begin.size();
+        if (prof) WN_HIP(ctx, hipEventRecord(ctx->prof_begin[ctx->prof_used], ctx->stream));
+        const void* wave64 = (lgR == 6 && lgC == 6 && ctx->wave64) ? wn_kernel_wave64(ctx->NP) : nullptr;
+        if (wave64) {
+            // one wave per example, four examples per workgroup; one partial-sum slot per wave
+            rc = launch(ctx, wave64, 256, (size_t)4 * wn::W64_TILE * sizeof(double), (B + 3) / 4, A, &grid, max_slots / 4);
+            grid *= 4;
+        } else if ((lgR == 8 || lgR == 9) && lgC == 0 && ctx->NP <= 8 && ctx->wave64) {
+            // 1D signals of 256 and 512 samples, up to 8 taps: one wave per example, cascade in registers
+            rc = launch(ctx, wn_kernel_wave1d_line(ctx->NP, 1 << (lgR - 6)), 64, (size_t)(512 + 8) * sizeof(double), B, A, &grid, max_slots);
+        } else if (lgR == 10 && lgC == 0 && ctx->wave64) {
+            // 1D signals of 1024 samples: one wave per example, one example in flight per workgroup
+            rc = launch(ctx, wn_kernel_wave1d(ctx->NP), 64, (size_t)(1024 + 8) * sizeof(double), B, A, &grid, max_slots);
+        } else {
+            // X, row-stage coefficients (2D only), pyramid, coefficients / sort slots, reduction scratch
+            const size_t shmem = ((size_t)(lgC > 0 ? 3 : 2) * R * C + S.NS + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double) + 16;
+            rc = launch(ctx, fused_kernel(ctx->NP, KIND_TRAIN, sc), S.T, shmem, B, A, &grid, max_slots);
+        }
+        if (rc) return rc;
+        if (prof) {
+            WN_HIP(ctx, hipEventRecord(ctx->prof_end[ctx->prof_used], ctx->stream));
+            ctx->prof_used++;
+        }
+    }
+    hipLaunchKernelGGL(k_reduce_partials, dim3(ctx->N + 2), dim3(64), 0, ctx->stream, partial, grid, ctx->N, sums);
+    WN_HIP(ctx, hipGetLastError());
+    return WN_OK;
+}
+
 int wn_train_batch(wn_context* ctx, const double* X, int B, int R, int C, double* grad, double* Sout) {
     int lgR, lgC, sc;
     int rc = check_shape(ctx, B, R, C, true, &lgR, &lgC, &sc);
@@ -645,41 +704,7 @@ int wn_train_batch(wn_context* ctx, const double* X, int B, int R, int C, double
         }
         return WN_OK;
     }
-    const SizeClass& S = kSizeClasses[sc < 0 ? 0 : sc];
-    wn::FusedArgs A;
-    memset(&A, 0, sizeof(A));
-    A.B = B; A.lgR = lgR; A.lgC = lgC; A.filt = ctx->dfilt;
-    A.X = X; A.grad = grad; A.S = Sout; A.partial = ctx->partial;
-    int grid = 0;
-    if (B > 0) {
-        const bool prof = ctx->prof_used < (int)ctx->prof_begin.size();
-        if (prof) WN_HIP(ctx, hipEventRecord(ctx->prof_begin[ctx->prof_used], ctx->stream));
-        const void* wave64 = (lgR == 6 && lgC == 6 && ctx->wave64) ? wn_kernel_wave64(ctx->NP) : nullptr;
-        if (wave64) {
-            // one wave per example, four examples per workgroup; one partial-sum slot per wave
-            rc = launch(ctx, wave64, 256, (size_t)4 * wn::W64_TILE * sizeof(double), (B + 3) / 4, A, &grid);
-            grid *= 4;
-        } else if ((lgR == 8 || lgR == 9) && lgC == 0 && ctx->NP <= 8 && ctx->wave64) {
-            // 1D signals of 256 and 512 samples, up to 8 taps: one wave per example, cascade in registers
-            rc = launch(ctx, wn_kernel_wave1d_line(ctx->NP, 1 << (lgR - 6)), 64, (size_t)(512 + 8) * sizeof(double), B, A, &grid);
-        } else if (lgR == 10 && lgC == 0 && ctx->wave64) {
-            // 1D signals of 1024 samples: one wave per example, one example in flight per workgroup
-            rc = launch(ctx, wn_kernel_wave1d(ctx->NP), 64, (size_t)(1024 + 8) * sizeof(double), B, A, &grid);
-        } else {
-            // X, row-stage coefficients (2D only), pyramid, coefficients / sort slots, reduction scratch
-            const size_t shmem = ((size_t)(lgC > 0 ? 3 : 2) * R * C + S.NS + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double) + 16;
-            rc = launch(ctx, fused_kernel(ctx->NP, KIND_TRAIN, sc), S.T, shmem, B, A, &grid);
-        }
-        if (rc) return rc;
-        if (prof) {
-            WN_HIP(ctx, hipEventRecord(ctx->prof_end[ctx->prof_used], ctx->stream));
-            ctx->prof_used++;
-        }
-        if (grid > ctx->partial_blocks) return fail(ctx, WN_ERR_STATE, "partial buffer too small");
-    }
-    hipLaunchKernelGGL(k_reduce_partials, dim3(ctx->N + 2), dim3(64), 0, ctx->stream, ctx->partial, grid, ctx->N, ctx->sums);
-    WN_HIP(ctx, hipGetLastError());
-    return WN_OK;
+    return train_fused(ctx, X, B, lgR, lgC, sc, grad, Sout, ctx->partial, ctx->partial_blocks, ctx->sums);
 }
 
 int wn_sums(wn_context* ctx, double** sums_dev, int* count) {
@@ -751,16 +776,32 @@ int wn_apply_update(wn_context* ctx, double batch_total, double lambda_sum, doub
     return WN_OK;
 }
 
+// steps and the non-finite flag sit side by side in FilterDev
+static int read_update_state(wn_context* ctx, int* steps, int* nonfinite) {
+    int two[2] = {0, 0};
+    static_assert(offsetof(wn::FilterDev, nonfinite) == offsetof(wn::FilterDev, steps) + sizeof(int), "layout");
+    const int rc = wn_memcpy_d2h(ctx, two, &ctx->dfilt->steps, sizeof(two));
+    *steps = two[0];
+    *nonfinite = two[1];
+    return rc;
+}
+
 int wn_num_updates(wn_context* ctx, int* steps) {
     if (!ctx || !steps) return WN_ERR_ARG;
-    return wn_memcpy_d2h(ctx, steps, &ctx->dfilt->steps, sizeof(int));
+    int bad = 0;
+    const int rc = read_update_state(ctx, steps, &bad);
+    if (rc) return rc;
+    if (bad)
+        return fail(ctx, WN_ERR_NONFINITE, "a batch gave non-finite sums and was not applied (most likely a diverging "
+                                           "solution: lower alpha or lambda); no update is applied until wn_set_filter or wn_clear_logs");
+    return WN_OK;
 }
 
 int wn_get_logs(wn_context* ctx, int first, int count, double* filters, double* costs) {
     if (!ctx || first < 0 || count < 0) return WN_ERR_ARG;
     if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
-    int steps = 0;
-    int rc = wn_num_updates(ctx, &steps);
+    int steps = 0, bad = 0;
+    int rc = read_update_state(ctx, &steps, &bad);
     if (rc) return rc;
     if (first + count > steps || steps - first > kLogCap)
         return fail(ctx, WN_ERR_ARG, "log range not available (" + std::to_string(steps) + " updates, ring of " +

@@ -33,6 +33,8 @@ struct FilterDev {
     double a_true[MAXTAPS];    // the N filter coefficients
     double momentum[MAXTAPS];  // SGD momentum (src/Wavenet.cxx:742-765)
     int N, NP, d, steps;
+    int nonfinite;             // set by the update kernel when a batch's sums were not finite; later updates are skipped
+    int reserved;
 };
 
 __device__ __forceinline__ unsigned swz(unsigned e) {

@@ -22,27 +22,12 @@
 namespace wn {
 
 
-// min -> lo, max -> hi.  Plain (not volatile) asm: two instructions, free to be scheduled.
+// min -> lo, max -> hi.
 __device__ __forceinline__ void cmpx_asm(double& lo, double& hi) {
     double mn, mx;
-#ifndef W64_CMPX_PLAIN
     asm volatile("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(mn), "=&v"(mx) : "v"(lo), "v"(hi));
-#else
-    asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(lo), "v"(hi));
-    asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(lo), "v"(hi));
-#endif
     lo = mn;
     hi = mx;
-}
-
-// Parks 64 doubles in accumulation registers until their next use.  The sort needs all the
-// architectural VGPRs it can get; saying where the bystanders go keeps them out of scratch memory,
-// and the opaque asm keeps expressions of them from being carried across in more registers.
-__device__ __forceinline__ void w64_park(double (&v)[64]) {
-#ifdef W64_PARK
-#pragma unroll
-    for (int r = 0; r < 64; r++) asm volatile("" : "+a"(v[r]));
-#endif
 }
 
 // Order point between LDS writes and the reads that follow: a wave's LDS operations execute in
@@ -189,9 +174,6 @@ __device__ __forceinline__ void w64_read_transposed(double (&v)[64], const doubl
 // the rest is still in flight.
 template <int FIRST = 0>
 __device__ __forceinline__ void w64_transpose(double (&v)[64], double* tile, int lane) {
-#ifdef W64_SKIP_TRANSPOSE
-    return;
-#endif
 #pragma unroll
     for (int r = 0; r < 64; r++) tile[lane * 65 + r] = v[r];
 #pragma unroll
@@ -213,9 +195,7 @@ template <int RB>
 __device__ __forceinline__ void w64_substage(double (&k)[64]) {
 #pragma unroll
     for (int r = 0; r < 64; r++) {
-#ifndef W64_SKIP_CMPX
         if (!(r & (1 << RB))) cmpx_asm(k[r], k[r | (1 << RB)]);
-#endif
     }
 }
 template <int RB>
@@ -323,9 +303,7 @@ __device__ __forceinline__ W64Rank w64_rank_sort(const double (&y)[64], double* 
         const unsigned idx = (unsigned)(r + 64 * lane);
         k[r] = __hiloint2double(__double2hiint(ay), (int)((((unsigned)__double2loint(ay)) & ~0xFFFu) | idx));
     }
-#ifndef W64_SKIP_SORT
     w64_merge<1>(k, tile, lane);
-#endif
     // Sorted position p = lane * 64 + r.  Everyone gets rank p + 1 first.
     w64_lds_order();
     unsigned short* rk = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(tile) + W64_OFF_RANK);
@@ -715,14 +693,12 @@ __global__ __launch_bounds__(256, 1) void k_train64(FusedArgs A) {
         double gL[NP], gH[NP];
 #pragma unroll
         for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
-#ifndef W64_SKIP_BWD
         w64_pyramid_to_tile<NP, 5>(w, p, trow, a);                // column pyramid into the lane's tile row
         w64_bwd_levels<NP, 0, W64_TOP_TILE, true>(v, w, trow, a, b, gL, gH);    // columns; errors on Y1(:, lane) to the tile
         w64_read_transposed(v, tile, lane);                        // v[c] = D1(lane, c): lane = row
         w64_load_rows(w, Xe, lane);
         w64_pyramid_to_tile<NP, 5>(w, p, trow, a);
         w64_bwd_levels<NP, 0, W64_TOP_NONE, true>(v, w, trow, a, b, gL, gH);   // rows
-#endif
 
         // tap k' collects gL[k'] and sH[k'] gH[NP-1-k'], summed over the 64 lanes
         double mine = 0;

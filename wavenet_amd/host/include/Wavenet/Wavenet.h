@@ -47,6 +47,9 @@ public:
     void clearFilterLog() { m_filterLog.clear(); }
     std::vector<double>& costLog() { return m_costLog; }
     void clearCostLog() { m_costLog.assign(1, 0.); }
+    // gradients queued for the pending batch (the reference keeps them private and carries them through
+    // its snapshots; Coach restores them between initialisations)
+    std::vector<Col>& batchQueue() { return m_batchQueue; }
     double firstCost() const;
     double lastCost() const;
 
@@ -131,6 +134,7 @@ private:
     // per-example results into the batch queue and the cost log (the slow, exact path of train()).
     bool trainOnDevice_(const double* dX, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas);
     bool queueExamples_(const double* X_dev, unsigned count, unsigned nRows, unsigned nCols, const double* lambdas);
+    bool diverged_() const;  // prints the reference's "diverging solution" message, returns false
 
     double m_lambda = 10.0;
     double m_alpha = 0.001;

@@ -59,6 +59,7 @@ bool Coach::run() {
     const double lambdaBare = m_wavenet->lambda();      // :123
     const double alphaBare = m_wavenet->alpha();        // the reference restores these from its base snapshot (:138)
     const unsigned batchBare = (unsigned)m_wavenet->batchSize();
+    const std::vector<Col> queueBare = m_wavenet->batchQueue();
     const std::vector<unsigned> shape = m_generator->shape();
     const unsigned nRows = shape[0], nCols = shape[1];
     const std::size_t n = (std::size_t)nRows * nCols;
@@ -72,6 +73,7 @@ bool Coach::run() {
         m_wavenet->setLambda(lambdaBare);
         m_wavenet->setAlpha(alphaBare);
         m_wavenet->setBatchSize(batchBare);
+        m_wavenet->batchQueue() = queueBare;
         m_wavenet->clear();                                                             // :139
         if (m_initialFilter.n_elem) m_wavenet->setFilter(m_initialFilter);
         else m_wavenet->setFilter(PointOnNSphere(m_numCoeffs, 0., m_seed + init));      // :144
@@ -79,6 +81,14 @@ bool Coach::run() {
         bool done = false;
         unsigned tail = 0;
         unsigned currentCostLogSize = 0, previousCostLogSize = 0;
+        // The reference compares the cost log's size after every EVENT (:196-204).  After the first event
+        // of an initialisation the size (1, no flush yet when the batch holds more than one example) differs
+        // from the initial 0, which already counts as a change and bumps `tail`.  Events come in whole
+        // batches here, so that first comparison is made up front.
+        if (adaptive && m_wavenet->batchSize() > 1 && m_numEvents != 0) {
+            currentCostLogSize = (unsigned)m_wavenet->costLog().size();
+            tail = 1;
+        }
 
         for (unsigned epoch = 0; epoch < m_numEpochs && !done; epoch++) {
             m_generator->reset();                                                       // :164

@@ -213,6 +213,9 @@ bool Wavenet::queueExamples_(const double* X_dev, unsigned count, unsigned nRows
     const double reg = RegTerm(m_filter, m_wavelet);
     for (unsigned e = 0; e < count; e++) {
         const double lambda = lambdas ? lambdas[e] : m_lambda;
+        bool finite = std::isfinite(S[e]);
+        for (int k = 0; k < N; k++) finite = finite && std::isfinite(G[(std::size_t)e * N + k]);
+        if (!finite) return diverged_();                                                // :234-241
         Col gradientCombined(N);
         for (int k = 0; k < N; k++) gradientCombined(k) = G[(std::size_t)e * N + k] + lambda * regDeriv(k);
         m_batchQueue.push_back(gradientCombined);
@@ -262,7 +265,8 @@ bool Wavenet::trainOnDevice_(const double* dX, unsigned B, unsigned nRows, unsig
             // whole batches back to back on the device: train kernel, batch reduction, update kernel
             // (at most 8192 per round trip: the device keeps the last 16384 log entries)
             const unsigned nb = std::min((B - done) / m_batchSize, 8192u);
-            const int firstLog = [&] { int s = 0; wn_num_updates(dev.ctx, &s); return s; }();
+            int firstLog = 0;
+            if (wn_num_updates(dev.ctx, &firstLog) == WN_ERR_NONFINITE) return diverged_();
             for (unsigned b = 0; b < nb; b++) {
                 const double* Xb = dX + (std::size_t)(done + b * m_batchSize) * n;
                 double lambdaSum = 0;
@@ -273,19 +277,24 @@ bool Wavenet::trainOnDevice_(const double* dX, unsigned B, unsigned nRows, unsig
                 if (!dev.ok(wn_apply_update(dev.ctx, (double)m_batchSize, lambdaSum, m_alpha, effectiveInertia_(steps), m_wavelet)))
                     return false;
             }
-            // bring the logs and the state back
-            std::vector<double> F((std::size_t)nb * N), C(nb);
-            if (!dev.ok(wn_get_logs(dev.ctx, firstLog, (int)nb, F.data(), C.data()))) return false;
-            for (unsigned b = 0; b < nb; b++) {
+            // bring the logs and the state back; a batch with non-finite sums was not applied, nor was any
+            // batch after it
+            int lastLog = 0;
+            const int state = wn_num_updates(dev.ctx, &lastLog);
+            if (state != WN_OK && state != WN_ERR_NONFINITE) return dev.ok(state);
+            const unsigned applied = (unsigned)(lastLog - firstLog);
+            std::vector<double> F((std::size_t)applied * N), C(applied);
+            if (applied && !dev.ok(wn_get_logs(dev.ctx, firstLog, (int)applied, F.data(), C.data()))) return false;
+            for (unsigned b = 0; b < applied; b++) {
                 m_filterLog.push_back(Col(N, F.data() + (std::size_t)b * N));
                 m_costLog.back() = C[b];
                 m_costLog.push_back(0);
-                if (!std::isfinite(C[b])) WARNING("Non-finite cost at update %zu: diverging solution?", m_costLog.size() - 1);
             }
-            m_filter = m_filterLog.back();
+            if (applied) m_filter = m_filterLog.back();
             int nn = N;
             if (!dev.ok(wn_get_momentum(dev.ctx, m_momentum.memptr(), &nn))) return false;
-            if (lambdas) m_lambda = lambdas[done + nb * m_batchSize - 1];
+            if (lambdas && applied) m_lambda = lambdas[done + applied * m_batchSize - 1];
+            if (state == WN_ERR_NONFINITE) return diverged_();                          // :234-241
             done += nb * m_batchSize;
         } else {
             // fill the pending batch (or a trailing partial one) example by example
@@ -295,6 +304,14 @@ bool Wavenet::trainOnDevice_(const double* dX, unsigned B, unsigned nRows, unsig
         }
     }
     return true;
+}
+
+// The reference's train() catches the exception a NaN raises, prints this and returns false
+// (src/Wavenet.cxx:234-241); Coach::run then ends the initialisation (src/Coach.cxx:186-189).
+bool Wavenet::diverged_() const {
+    ERROR("Non-finite cost or gradient.");
+    ERROR("Most likely due to diverging solution. Try lowering the learning rate (alpha) or the regularisation term (lambda). Exiting.");
+    return false;
 }
 
 void Wavenet::clear() {

@@ -39,6 +39,9 @@ class DataParallelTrainer:
         self.ctx = ctx
         self.world_size = world_size
         self.group = group
+        # the all-reduce is ordered on torch's current stream: the context's kernels must be on it too,
+        # or the collective could read the sums before the batch reduction has written them
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         self._buf = torch.zeros(WN_MAX_TAPS + 2, dtype=torch.float64, device="cuda")
         ctx.set_sums_buffer(self._buf)
 
