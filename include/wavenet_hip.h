@@ -146,6 +146,24 @@ int wn_train_batch(wn_context* ctx, const double* X_dev, int B, int R, int C,
                    double* grad_dev, double* S_dev);
 
 /*
+ * wn_train_batch without any allocation.  It has no counterpart in the reference; it is for callers that
+ * cannot call hipMalloc: code under HIP graph capture, tight serving loops, harnesses that forbid it.
+ * Same kernels as wn_train_batch, but the per-workgroup partial sums -- the one scratch buffer of that
+ * path, which the context otherwise holds in memory it allocated -- go to a fixed array inside the library's
+ * code object (WN_STATIC_SLOTS slots of WN_MAX_TAPS + 2 doubles, 2.1 MiB, held by every GPU the library is
+ * used on until the process ends), and the N + 2 sums are written to sums_dev, the caller's device memory
+ * (not to the context's sum buffer).  No per-example outputs.  Examples of up to WN_MAX_FUSED samples, any
+ * B; a larger example is refused with WN_ERR_UNSUPPORTED (its path needs a workspace that grows with the
+ * batch).  The call makes no hipMalloc / hipFree and nothing else that allocates device memory; the first
+ * call for a shape and filter length also queries that kernel's occupancy, so make one call before a
+ * capture.  All calls on one GPU share the array (whatever context or stream they come through): calls
+ * that overlap in time on one GPU race; calls on one stream, or otherwise ordered, do not.  Nothing in
+ * the array has to be zero beforehand (every slot that is read was written by the same call).
+ */
+#define WN_STATIC_SLOTS 8192
+int wn_train_batch_static(wn_context* ctx, const double* X_dev, int B, int R, int C, double* sums_dev);
+
+/*
  * Device pointer to the N + 2 sums of the last wn_train_batch on this context, for the caller's
  * all-reduce over data-parallel ranks (sum), e.g. torch.distributed / RCCL on the same stream.
  */

@@ -50,6 +50,7 @@ SIGNATURES = {
     "wn_generate_calorimeter": (C.c_int, [_vp, C.c_ulonglong, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                           C.POINTER(C.c_int), _dp, C.c_int, C.c_int, _vp]),
     "wn_train_batch": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "wn_train_batch_static": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "wn_sums": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_int)]),
     "wn_get_sums": (C.c_int, [_vp, _dp, C.POINTER(C.c_int)]),
     "wn_set_sums_buffer": (C.c_int, [_vp, _vp]),
@@ -258,6 +259,10 @@ class Context:
     # training -----------------------------------------------------------------------------------
     def train_batch(self, X, B, R, Cc, grad=None, S=None):
         self._check(self.lib.wn_train_batch(self._h, _addr(X), B, R, Cc, _addr(grad), _addr(S)))
+
+    def train_batch_static(self, X, B, R, Cc, sums):
+        """wn_train_batch_static: no allocation; sums: device tensor/address of N + 2 doubles."""
+        self._check(self.lib.wn_train_batch_static(self._h, _addr(X), B, R, Cc, _addr(sums)))
 
     def sums_ptr(self):
         p = _vp()

@@ -43,6 +43,15 @@ const int kLogCap = 16384;
 
 }  // namespace
 
+// Partial sums of wn_train_batch_static: a fixed array in the code object instead of memory from hipMalloc,
+// for callers that cannot allocate.  Every GPU the library runs on holds its own copy at its own address;
+// scratch_ptr[device] is that address, looked up once per device in wn_create.  In host code the array's
+// name is only a handle for that look-up, never a device address.
+constexpr int kStaticSlots = WN_STATIC_SLOTS;
+static __device__ __align__(256) double scratch[(size_t)kStaticSlots * wn::PSTRIDE];
+constexpr int kMaxDevices = 64;
+static double* scratch_ptr[kMaxDevices];
+
 namespace {
 
 using wn::fail;
@@ -287,6 +296,21 @@ int wn_create(int device, wn_context** out) {
         return WN_ERR_HIP;
     }
     ctx->numCU = prop.multiProcessorCount;
+    if (device < 0 || device >= kMaxDevices) {
+        wn::global_error() = "device number beyond " + std::to_string(kMaxDevices - 1);
+        delete ctx;
+        return WN_ERR_ARG;
+    }
+    if (!scratch_ptr[device]) {   // this device is current: the address is the one of its copy
+        double* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            wn::global_error() = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+            delete ctx;
+            return WN_ERR_HIP;
+        }
+        scratch_ptr[device] = p;
+    }
     int rc = WN_OK;
     auto alloc = [&](void** p, size_t bytes) {
         hipError_t ee = hipMalloc(p, bytes);
@@ -705,6 +729,21 @@ int wn_train_batch(wn_context* ctx, const double* X, int B, int R, int C, double
         return WN_OK;
     }
     return train_fused(ctx, X, B, lgR, lgC, sc, grad, Sout, ctx->partial, ctx->partial_blocks, ctx->sums);
+}
+
+int wn_train_batch_static(wn_context* ctx, const double* X, int B, int R, int C, double* sums_dev) {
+    int lgR, lgC, sc;
+    int rc = check_shape(ctx, B, R, C, true, &lgR, &lgC, &sc);
+    if (rc) return rc;
+    if (!sums_dev) return fail(ctx, WN_ERR_ARG, "null output");
+    if (B > 0 && !X) return fail(ctx, WN_ERR_ARG, "null input");
+    if (sc < 0)
+        return fail(ctx, WN_ERR_UNSUPPORTED,
+                    "wn_train_batch_static: examples of " + std::to_string((long long)R * C) + " samples exceed the " +
+                        std::to_string(WN_MAX_FUSED) + " it takes (larger ones need a workspace that grows with the batch: use wn_train_batch)");
+    double* part = scratch_ptr[ctx->device];
+    if (!part) return fail(ctx, WN_ERR_STATE, "the static scratch array was not located on this device");
+    return train_fused(ctx, X, B, lgR, lgC, sc, nullptr, nullptr, part, kStaticSlots, sums_dev);
 }
 
 int wn_sums(wn_context* ctx, double** sums_dev, int* count) {
