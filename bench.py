@@ -1,13 +1,16 @@
 #!/usr/bin/env python
-"""Headline benchmark: training examples/s of the Wavenet hot path (forward + Gini gradient +
-backpropagation + batch reduction + filter update) on MI355X, one process per GPU.
+"""Benchmark of the Wavenet training hot path (forward + Gini gradient + backpropagation + batch
+reduction + filter update) on MI355X, one process per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME|all|headline] [--scaling weak|strong]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step is one pass of the hot path over one batch resident in HBM.  The default workload is the
-configuration BASELINE.json's metric is quoted on: 2D 64x64 calorimeter-style images, batch 4096
-per GPU (weak scaling), 4-tap filter.  Prints one JSON line on rank 0.
+A step is one pass of the hot path over one batch resident in HBM.  Rank 0 prints one JSON line per
+workload; the LAST line is the headline, the configuration BASELINE.json's metric is quoted on: 2D 64x64
+calorimeter-style images, batch 4096 per GPU, 4-tap filter.  On one GPU the default run first prints a
+line each for the other configurations (64x64 with 16 taps, 1D 1024 / 16 taps, the per-GPU slices of
+512x512 / batch 16384 over 8 GPUs and of 2^20-sample signals / 32 taps); with more ranks only the headline
+is run unless --workload says otherwise.
 """
 import argparse
 import json
@@ -24,11 +27,24 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec), GB/s
 
 WORKLOADS = {
-    # name: (R, C, per-GPU batch, default taps, generator)
-    "2d64": (64, 64, 4096, 4, "calorimeter"),
-    "1d1024": (1024, 1, 4096, 16, "bumps"),
-    "2d512": (512, 512, 2048, 4, "calorimeter"),    # streamed path; 16384 images over 8 GPUs
-    "1d1m": (1 << 20, 1, 8, 32, "bumps"),           # streamed path, 8 signals per GPU
+    # name: (R, C, per-GPU batch, taps, generator, seconds of CPU baseline)
+    "2d64": (64, 64, 4096, 4, "calorimeter", 15.0),
+    "2d64n16": (64, 64, 4096, 16, "calorimeter", 6.0),
+    "1d1024": (1024, 1, 4096, 16, "bumps", 6.0),
+    "2d512": (512, 512, 2048, 4, "calorimeter", 8.0),    # streamed path; 16384 images over 8 GPUs
+    "1d1m": (1 << 20, 1, 8, 32, "bumps", 6.0),           # streamed path, 8 signals per GPU
+}
+HEADLINE = "2d64"
+ALL_ORDER = ["2d64n16", "1d1024", "2d512", "1d1m", HEADLINE]
+
+# What actually limits the dominant kernel (the graded roofline fraction prices the step in the bytes an
+# unfused pipeline would move; these kernels keep most of those passes on chip).
+LIMITER = {
+    "2d64": "VALU/LDS issue: the 4096-key bitonic sort of the Gini ranks is about half of the kernel's cycles",
+    "2d64n16": "VALU issue (filter cascade and sort) with one wave per SIMD",
+    "1d1024": "VALU issue: the Gini phase (sort and ranks) is most of the kernel's instructions",
+    "2d512": "HBM passes of the per-example ranking and of the four line-transform kernels",
+    "1d1m": "kernel count and tail latency: 8 signals per step give each launch little work",
 }
 
 
@@ -47,7 +63,7 @@ def make_inputs(gen, B, R, C, seed):
     return G.uniform(B, R, C, seed=seed)
 
 
-def cpu_baseline(X, a0, lam, alpha, budget_s=15.0):
+def cpu_baseline(X, a0, lam, alpha, budget_s):
     """Times the dense CPU restatement of the reference path (oracle/, one thread) on a bounded
     sample of the same examples: Wavenet::train per example, one batch update at the end."""
     from oracle import oracle as orc  # baseline leg only
@@ -64,82 +80,72 @@ def cpu_baseline(X, a0, lam, alpha, budget_s=15.0):
         return {"value": count / dt, "unit": "examples/s", "cores": 1, "kind": "port",
                 "sample": f"{count} of the benchmark's examples through the BANDED restatement (forward, Gini gradient, "
                           f"backpropagation; the reference's dense operators would need 4 TiB at this length), {dt:.1f} s"}
-    probe = 16
-    w = orc.Wavenet(lam=lam, alpha=alpha)
-    w.set_batch_size(1 << 30)
-    w.set_filter(a0)
-    t0 = time.perf_counter()
-    for e in range(probe):
-        w.train(X[e])
-    per = (time.perf_counter() - t0) / probe
+
+    def run(count):
+        w = orc.Wavenet(lam=lam, alpha=alpha)
+        w.set_batch_size(max(count, 2))
+        w.set_filter(a0)
+        t0 = time.perf_counter()
+        for e in range(count):
+            w.train(X[e])
+        if count < 2:
+            w.flush()
+        return time.perf_counter() - t0
+
+    per = run(1)                                   # also builds the weight matrices once, as the reference does
+    probe = int(max(1, min(8, len(X), 0.2 * budget_s / max(per, 1e-9))))
+    per = run(probe) / probe
     count = int(max(probe, min(len(X), budget_s / max(per, 1e-9))))
-    w = orc.Wavenet(lam=lam, alpha=alpha)
-    w.set_batch_size(count)
-    w.set_filter(a0)
-    t0 = time.perf_counter()
-    for e in range(count):
-        w.train(X[e])
-    dt = time.perf_counter() - t0
+    dt = run(count)
     return {"value": count / dt, "unit": "examples/s", "cores": 1, "kind": "port",
             "sample": f"{count} of the benchmark's examples through the dense restatement "
                       f"(matrix operators rebuilt per update, plain loops instead of BLAS), {dt:.1f} s"}
 
 
-def load_traffic(workload, taps):
-    """HBM bytes per training-kernel launch from the committed rocprofv3 PMC passes, if present."""
+def load_traffic(workload):
+    """HBM bytes per step from the committed rocprofv3 PMC passes (profiles/traffic.json), if present."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(f"{workload}_n{taps}")
+            return json.load(f).get(workload)
     except (OSError, ValueError):
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="2d64", choices=sorted(WORKLOADS))
-    ap.add_argument("--taps", type=int, default=0, help="filter length N (default: per workload)")
-    ap.add_argument("--batch", type=int, default=0, help="examples per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
+def run_workload(name, args, rank, local_rank, world, dist):
     import torch
     from wavenet_amd import Context
     from wavenet_amd.filters import daubechies, perturbed
     from wavenet_amd.generators import to_device_layout
-    from wavenet_amd.parallel import DataParallelTrainer, dist_env
+    from wavenet_amd.parallel import DataParallelTrainer, shard_range
 
-    rank, local_rank, world = dist_env()
-    if args.gpus != world:
-        if world == 1:
-            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with "
-                     f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py ...")
-        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    R, C, B, N, gen = WORKLOADS[args.workload]
+    R, C, B, N, gen, cpu_budget = WORKLOADS[name]
     if args.taps:
         N = args.taps
     if args.batch:
         B = args.batch
+    if args.scaling == "strong":
+        # the global batch is what one GPU takes in the weak form; every rank trains its contiguous share
+        global_batch = B
+        first, last = shard_range(global_batch, rank, world)
+        B = last - first
+    else:
+        global_batch = B * world
+        first = rank * B
     lam, alpha = 10.0, 1e-3
     a0 = perturbed(daubechies(N), 1e-2, seed=7)
 
     ctx = Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
     X = None
+    seed = 1000
     if gen == "calorimeter":
-        # generated on the device (bit-identical to generators.calorimeter; tests/test_gpu_generators.py)
-        dX = torch.empty(B * R * C, dtype=torch.float64, device="cuda")
+        # generated on the device (bit-identical to generators.calorimeter; tests/test_gpu_generators.py);
+        # example numbers continue across ranks, so the ranks hold disjoint parts of one sequence
+        dX = torch.empty(max(B, 1) * R * C, dtype=torch.float64, device="cuda")
         for e0 in range(0, B, 32768):
-            ctx.generate_calorimeter(dX[e0 * R * C:], min(32768, B - e0), R, C, seed=1000 + rank, first=e0)
+            ctx.generate_calorimeter(dX[e0 * R * C:], min(32768, B - e0), R, C, seed=seed, first=first + e0)
     else:
-        X = make_inputs(gen, B, R, C, seed=1000 + rank)
+        X = make_inputs(gen, first + B, R, C, seed=seed)[first:]
         dX = torch.from_numpy(to_device_layout(X)).cuda()
     ctx.set_filter(a0)
     trainer = DataParallelTrainer(ctx, world)
@@ -150,12 +156,16 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        trainer.step(dX, B, R, C, lam, alpha)
-    ctx.profile_begin(args.steps)
+        trainer.step(dX, B, R, C, lam, alpha, B_total=global_batch)
+    # device time of the timed region: a pair of events on the stream the kernels are launched on (the
+    # context runs on torch's current stream)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     sync_all()
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
-        trainer.step(dX, B, R, C, lam, alpha)
+        trainer.step(dX, B, R, C, lam, alpha, B_total=global_batch)
+    ev1.record()
     torch.cuda.synchronize()
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -163,42 +173,107 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    device_ms = ev0.elapsed_time(ev1) / args.steps      # per step: one launch of the fused kernels
 
-    kernel_ms = ctx.profile_collect(args.steps)
     sums = trainer.sums()
     nonfinite = float(sums[-1])
     final_filter = ctx.filter()
 
+    out = None
     if rank == 0:
-        value = world * B * args.steps / elapsed
-        kavg = float(np.mean(kernel_ms)) * 1e-3
+        value = global_batch * args.steps / elapsed
+        kavg = device_ms * 1e-3
         achieved = B * algorithmic_bytes(R, C) / kavg / 1e9
+        traffic = load_traffic(name) if not (args.taps or args.batch) and args.scaling == "weak" else None
+        streamed = R * C > 4096
+        kernel = ("streamed path: all kernels of one wn_train_step" if streamed else
+                  "k_train64" if (R == 64 and C == 64) else
+                  "k_train1d1024" if (R == 1024 and C == 1) else "k_train")
         out = {
             "metric": f"training examples/sec (fwd+backprop+update), {'2D' if C > 1 else '1D'} {R}x{C}",
             "value": value, "unit": "examples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{'2D' if C > 1 else '1D'} Wavenet, {R}x{C} {gen} inputs, {N}-tap filter, "
-                                   f"batch {B} per GPU, Coach batch loop (lambda {lam}, alpha {alpha})",
-                       "shape": [R, C], "taps": N, "batch_per_gpu": B, "global_batch": B * world,
+                                   f"batch {B} on this GPU ({global_batch} over {world}), Coach batch loop (lambda {lam}, alpha {alpha})",
+                       "name": name, "shape": [R, C], "taps": N, "batch_per_gpu": B, "global_batch": global_batch,
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(args.workload, N),
-                         "kernel": ("streamed path, all kernels of wn_train_batch" if R * C > 4096 else
-                                    "k_train64" if (R == 64 and C == 64) else
-                                    "k_train1d1024" if (R == 1024 and C == 1) else "k_train"), "kernel_ms": kavg * 1e3,
-                         "algorithmic_bytes_per_launch": B * algorithmic_bytes(R, C)},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": kernel + (" (one launch per step: training, batch reduction and update)" if not streamed and world == 1 else ""),
+                         "kernel_ms": device_ms,
+                         "algorithmic_bytes_per_launch": B * algorithmic_bytes(R, C),
+                         "measured_hbm_GBs": (traffic / kavg / 1e9) if traffic else None,
+                         "limiter": LIMITER.get(name)},
             "nonfinite": nonfinite,
             "final_filter": [float(v) for v in final_filter],
         }
         if world == 1 and not args.no_cpu_baseline:
             if X is None:
                 # the same sequence of examples, on the host: no more of them than the sample can use
-                X = make_inputs(gen, min(2 * B, 16384, max(64, (1 << 24) // (R * C))), R, C, seed=1000 + rank)
-            out["cpu_baseline"] = cpu_baseline(X, a0, lam, alpha)
+                X = make_inputs(gen, min(B, 4096, max(4, (1 << 23) // (R * C))), R, C, seed=seed)
+            out["cpu_baseline"] = cpu_baseline(X, a0, lam, alpha, cpu_budget * args.cpu_scale)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
     ctx.close()
+    del dX
+    torch.cuda.empty_cache()
+    return out
+
+
+def workload_names(args, world):
+    if args.workload == "all" or (args.workload == "default" and world == 1 and not (args.taps or args.batch)):
+        return ALL_ORDER
+    if args.workload in ("default", "headline"):
+        return [HEADLINE]
+    return [args.workload]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="default", choices=sorted(WORKLOADS) + ["all", "headline", "default"],
+                    help="default: every configuration on one GPU (headline last), the headline alone on several")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the per-GPU batch is fixed; strong: the global batch is fixed and split over the ranks")
+    ap.add_argument("--taps", type=int, default=0, help="filter length N (default: per workload)")
+    ap.add_argument("--batch", type=int, default=0, help="examples per GPU per step (weak) / in all (strong)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scale", type=float, default=1.0, help="scales the seconds spent on the CPU baselines")
+    ap.add_argument("--dry-run", action="store_true", help="print what each rank would run (no GPU is touched)")
+    args = ap.parse_args()
+
+    from wavenet_amd.parallel import dist_env, shard_range
+
+    rank, local_rank, world = dist_env()
+    if args.gpus != world:
+        if world == 1:
+            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with "
+                     f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py ...")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        plan = []
+        for name in workload_names(args, world):
+            B = args.batch or WORKLOADS[name][2]
+            if args.scaling == "strong":
+                lo, hi = shard_range(B, rank, world)
+                plan.append({"name": name, "first": lo, "batch": hi - lo, "global_batch": B})
+            else:
+                plan.append({"name": name, "first": rank * B, "batch": B, "global_batch": B * world})
+        print(json.dumps({"rank": rank, "world": world, "scaling": args.scaling, "plan": plan}), flush=True)
+        return
+    import torch
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    for name in workload_names(args, world):
+        line = run_workload(name, args, rank, local_rank, world, dist)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -194,6 +194,20 @@ int wn_set_sums_buffer(wn_context* ctx, double* sums_dev);
 int wn_apply_update(wn_context* ctx, double batch_total, double lambda_sum, double alpha,
                     double inertia_eff, int do_wavelet);
 
+/*
+ * One whole batch of Coach's loop in one submission: wn_train_batch (without per-example outputs), the
+ * all-reduce of the sums when the context has a communicator of more than one rank (wn_comm_init), and
+ * wn_apply_update -- src/Wavenet.cxx:184-242 for B examples followed by flushBatchQueue_ (:717-765).
+ * Same arithmetic, same results as the three calls.  For 64x64 examples the batch reduction (and,
+ * without a communicator, the update) runs inside the training kernel, in the workgroup that finishes
+ * last, so a step is ONE kernel launch; for the other shapes of up to WN_MAX_FUSED samples it is the
+ * training kernel plus one launch that reduces and updates.  Either way consecutive steps queue up on
+ * the stream with no host code between them.  batch_total is the batch size over all ranks, B this
+ * rank's share of it.
+ */
+int wn_train_step(wn_context* ctx, const double* X_dev, int B, int R, int C, double batch_total,
+                  double lambda_sum, double alpha, double inertia_eff, int do_wavelet);
+
 /* Number of updates applied since the context was created or wn_clear_logs (wn_set_filter does not
  * reset it).  Returns WN_ERR_NONFINITE (with *steps filled in) once a batch was rejected for
  * non-finite sums.  Synchronises. */

@@ -57,6 +57,7 @@ SIGNATURES = {
     "wn_profile_begin": (C.c_int, [_vp, C.c_int]),
     "wn_profile_collect": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]),
     "wn_apply_update": (C.c_int, [_vp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
+    "wn_train_step": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
     "wn_num_updates": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "wn_get_logs": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp]),
     "wn_clear_logs": (C.c_int, [_vp]),
@@ -293,6 +294,11 @@ class Context:
     def apply_update(self, batch_total, lambda_sum, alpha, inertia_eff=0.0, wavelet=True):
         self._check(self.lib.wn_apply_update(self._h, float(batch_total), float(lambda_sum), float(alpha),
                                              float(inertia_eff), int(wavelet)))
+
+    def train_step(self, X, B, R, Cc, batch_total, lambda_sum, alpha, inertia_eff=0.0, wavelet=True):
+        """wn_train_step: train_batch + (all-reduce over the context's communicator) + apply_update, one submission."""
+        self._check(self.lib.wn_train_step(self._h, _addr(X), B, R, Cc, float(batch_total), float(lambda_sum),
+                                           float(alpha), float(inertia_eff), int(wavelet)))
 
     def num_updates(self):
         n = C.c_int(0)

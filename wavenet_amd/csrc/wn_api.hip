@@ -140,99 +140,32 @@ int launch(wn_context* ctx, const void* func, int T, size_t shmem, int B, wn::Fu
 __global__ __launch_bounds__(64) void k_reduce_partials(const double* partial, int nslots, int N, double* sums) {
     const int t = blockIdx.x, lane = threadIdx.x;
     if (t > N + 1) return;
-    double s = 0;
-    for (int slot = lane; slot < nslots; slot += 64) s += partial[(size_t)slot * wn::PSTRIDE + t];
-    s = wn::wave_sum(s);
+    const double s = wn::reduce_slots(partial, nslots, wn::PSTRIDE, t, lane);
     if (lane == 0) sums[t] = s;
 }
 
-__device__ void write_padded_filter(wn::FilterDev* f, const double* a) {
-    const int N = f->N, d = f->d;
-    for (int j = 0; j < wn::MAXTAPS; j++) { f->a[j] = 0; f->b[j] = 0; }
-    for (int j = 0; j < N; j++) {
-        f->a_true[j] = a[j];
-        f->a[j + d] = a[j];
-        f->b[j + d] = wn::parity_sign(j) * a[N - 1 - j];
-    }
+// Wavenet::flushBatchQueue_ / update_ / setFilter (src/Wavenet.cxx:717-765, 8-36) as a launch of its own:
+// after an all-reduce over ranks, and for examples that take the streamed path (wn_step.h has the body).
+__global__ __launch_bounds__(64) void k_update(wn::FilterDev* f, const double* sums, wn::UpdateParams P) {
+    __shared__ wn::UpdateShared sh;
+    wn::update_body(f, sums, P, sh, (int)threadIdx.x);
 }
 
-// Wavenet::flushBatchQueue_ / update_ / setFilter (src/Wavenet.cxx:717-765, 8-36), one wave: lane l
-// evaluates lag m = l - N/2 of the regularisation sums, lane i adds them up for tap i in the
-// reference's order.
-__global__ __launch_bounds__(64) void k_update(wn::FilterDev* f, const double* sums, double Bf, double lambda_sum,
-                                               double alpha, double inertia_eff, int wavelet, double* logF,
-                                               double* logC, int cap) {
-    __shared__ double a[wn::MAXTAPS], b[wn::MAXTAPS], prefA[wn::MAXTAPS + 1], prefB[wn::MAXTAPS + 1];
-    __shared__ float devA[wn::MAXTAPS + 1], devB[wn::MAXTAPS + 1];
-    __shared__ double anew[wn::MAXTAPS], pnew[wn::MAXTAPS], cost;
-    const int t = threadIdx.x;
-    const int N = f->N;
-    // A batch whose sums are not finite is not applied (the reference's train() fails before anything is
-    // queued, src/Wavenet.cxx:234-241), and neither is any batch after it: the flag stays up until
-    // wn_set_filter / wn_clear_logs.
-    const bool bad_here = (t <= N && !isfinite(sums[t])) || (t == N + 1 && sums[t] != 0.0);
-    if (__any(bad_here) || f->nonfinite) {
-        if (t == 0) f->nonfinite = 1;
-        return;
-    }
-    if (t < N) a[t] = f->a_true[t];
-    __syncthreads();
-    if (t < N) b[t] = wn::parity_sign(t) * a[N - t - 1];
-    __syncthreads();
-    if (t <= N) {
-        const int m = t - N / 2;
-        prefA[t] = wn::lag_prefactor(a, N, m);
-        devA[t] = wn::lag_deviation_sq_float(a, N, m);
-        prefB[t] = wn::lag_prefactor(b, N, m);
-        devB[t] = wn::lag_deviation_sq_float(b, N, m);
+// Batch reduction and update in one launch, for the training kernels whose many small workgroups leave too
+// many partial-sum slots for one workgroup's tail: wave w adds up quantities w, w + 16, ... (the order of
+// k_reduce_partials), then the first wave updates the filter (mode 2) -- or the sums are left for the
+// caller's all-reduce (mode 1).
+__global__ __launch_bounds__(1024) void k_finish(const double* partial, int nslots, wn::StepTail S) {
+    __shared__ double ssum[wn::PSTRIDE];
+    __shared__ wn::UpdateShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = S.filt->N;
+    for (int q = wave; q <= N + 1; q += 16) {
+        const double s = wn::reduce_slots(partial, nslots, wn::PSTRIDE, q, lane);
+        if (lane == 0) { ssum[q] = s; S.sums[q] = s; }
     }
     __syncthreads();
-    const double suma = wn::sum_taps(a, N), sumb = wn::sum_taps(b, N);
-    if (t < N) {
-        double regd = 0;                                                            // RegTermDeriv, tap t
-        for (int l = 0; l <= N; l++) regd += prefA[l] * wn::lag_inner(a, N, t, l - N / 2);
-        if (wavelet) {
-            regd += 2 * (suma - 1.4142135623730951) * 1.0;
-            for (int l = 0; l <= N; l++) regd += prefB[l] * wn::lag_inner(a, N, t, l - N / 2);
-            regd += 2 * (sumb - 0) * wn::parity_sign(N - t - 1);
-        }
-        double gbar = sums[t] + lambda_sum * regd;
-        gbar /= Bf;                                   // gradient /= float(size)          :727
-        double p = f->momentum[t] * inertia_eff;      // scaleMomentum_                    :760
-        p += -alpha * gbar;                           // addMomentum_                      :761
-        pnew[t] = p;
-        anew[t] = a[t] + p;                           // setFilter(m_filter + m_momentum)  :762
-    }
-    if (t == 0) {
-        double reg = 0.;                                                            // RegTerm
-        float R2 = 0.f;
-        for (int l = 0; l <= N; l++) R2 = R2 + devA[l];
-        reg += R2;
-        if (wavelet) {
-            const double c1 = suma - 1.4142135623730951;
-            reg += c1 * c1;
-            float R3 = 0.f;
-            for (int l = 0; l <= N; l++) R3 = R3 + devB[l];
-            reg += R3;
-            reg += sumb * sumb;
-        }
-        reg = reg / 2.;
-        cost = (sums[N] + lambda_sum * reg) / Bf;                                   // :227, :733
-    }
-    __syncthreads();
-    // the same for a filter or a cost that overflowed on the way
-    if (__any(t < N && !isfinite(anew[t])) || !isfinite(cost)) {
-        if (t == 0) f->nonfinite = 1;
-        return;
-    }
-    if (t < N) f->momentum[t] = pnew[t];
-    if (t == 0) {
-        const int idx = f->steps % cap;
-        logC[idx] = cost;
-        f->steps = f->steps + 1;
-        for (int k = 0; k < wn::MAXTAPS; k++) logF[(size_t)idx * wn::MAXTAPS + k] = (k < N) ? anew[k] : 0.0;
-        write_padded_filter(f, anew);
-    }
+    if (S.mode == 2) wn::update_body(S.filt, ssum, S.P, sh, tid);
 }
 
 __global__ void k_reset_steps(wn::FilterDev* f) {
@@ -325,6 +258,7 @@ int wn_create(int device, wn_context** out) {
     if (rc == WN_OK) alloc((void**)&ctx->dfilt, sizeof(wn::FilterDev));
     if (rc == WN_OK) alloc((void**)&ctx->partial, (size_t)ctx->partial_blocks * wn::PSTRIDE * sizeof(double));
     if (rc == WN_OK) alloc((void**)&ctx->own_sums, wn::PSTRIDE * sizeof(double));
+    if (rc == WN_OK) alloc((void**)&ctx->ticket, 256);
     ctx->sums = ctx->own_sums;
     if (rc == WN_OK) alloc((void**)&ctx->log_filters, (size_t)kLogCap * wn::MAXTAPS * sizeof(double));
     if (rc == WN_OK) alloc((void**)&ctx->log_costs, (size_t)kLogCap * sizeof(double));
@@ -344,6 +278,7 @@ int wn_destroy(wn_context* ctx) {
     (void)hipFree(ctx->dfilt);
     (void)hipFree(ctx->partial);
     (void)hipFree(ctx->own_sums);
+    (void)hipFree(ctx->ticket);
     (void)hipFree(ctx->workspace);
     if (ctx->gen_tables) (void)hipFree(ctx->gen_tables);
     if (ctx->grid_filters) (void)hipFree(ctx->grid_filters);
@@ -673,31 +608,36 @@ int wn_sparse_cost_grid(wn_context* ctx, const double* X, int B, int R, int C, c
 // The LDS-resident and one-wave-per-example training kernels plus the batch reduction: per-workgroup (per-wave)
 // sums go to `partial` (room for max_slots slots), the N + 2 sums to `sums`.
 static int train_fused(wn_context* ctx, const double* X, int B, int lgR, int lgC, int sc, double* grad, double* Sout,
-                       double* partial, int max_slots, double* sums) {
+                       double* partial, int max_slots, double* sums, const wn::StepTail* tail = nullptr) {
     const int R = 1 << lgR, C = 1 << lgC;
     const SizeClass& S = kSizeClasses[sc < 0 ? 0 : sc];
     wn::FusedArgs A;
     memset(&A, 0, sizeof(A));
     A.B = B; A.lgR = lgR; A.lgC = lgC; A.filt = ctx->dfilt;
     A.X = X; A.grad = grad; A.S = Sout; A.partial = partial;
+    const void* wave64 = (lgR == 6 && lgC == 6 && ctx->wave64) ? wn_kernel_wave64(ctx->NP) : nullptr;
+    // k_train64's last workgroup ends the step itself (wn_step.h); the kernels of many small workgroups
+    // leave that to k_finish
+    const bool in_kernel_tail = tail && B > 0 && wave64;
+    if (in_kernel_tail) A.tail = *tail;
     int grid = 0, rc = WN_OK;
     if (B > 0) {
         const bool prof = ctx->prof_used < (int)ctx->prof_begin.size();
         if (prof) WN_HIP(ctx, hipEventRecord(ctx->prof_begin[ctx->prof_used], ctx->stream));
-        const void* wave64 = (lgR == 6 && lgC == 6 && ctx->wave64) ? wn_kernel_wave64(ctx->NP) : nullptr;
         if (wave64) {
             // one wave per example, four examples per workgroup; one partial-sum slot per wave
             rc = launch(ctx, wave64, 256, (size_t)4 * wn::W64_TILE * sizeof(double), (B + 3) / 4, A, &grid, max_slots / 4);
             grid *= 4;
         } else if ((lgR == 8 || lgR == 9) && lgC == 0 && ctx->NP <= 8 && ctx->wave64) {
             // 1D signals of 256 and 512 samples, up to 8 taps: one wave per example, cascade in registers
-            rc = launch(ctx, wn_kernel_wave1d_line(ctx->NP, 1 << (lgR - 6)), 64, (size_t)(512 + 8) * sizeof(double), B, A, &grid, max_slots);
+            rc = launch(ctx, wn_kernel_wave1d_line(ctx->NP, 1 << (lgR - 6)), 64, std::max<size_t>((512 + 8) * sizeof(double), wn::TAIL_LDS_BYTES), B, A, &grid, max_slots);
         } else if (lgR == 10 && lgC == 0 && ctx->wave64) {
             // 1D signals of 1024 samples: one wave per example, one example in flight per workgroup
             rc = launch(ctx, wn_kernel_wave1d(ctx->NP), 64, (size_t)(1024 + 8) * sizeof(double), B, A, &grid, max_slots);
         } else {
             // X, row-stage coefficients (2D only), pyramid, coefficients / sort slots, reduction scratch
-            const size_t shmem = ((size_t)(lgC > 0 ? 3 : 2) * R * C + S.NS + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double) + 16;
+            const size_t shmem = std::max<size_t>(((size_t)(lgC > 0 ? 3 : 2) * R * C + S.NS + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double) + 16,
+                                                  wn::TAIL_LDS_BYTES);
             rc = launch(ctx, fused_kernel(ctx->NP, KIND_TRAIN, sc), S.T, shmem, B, A, &grid, max_slots);
         }
         if (rc) return rc;
@@ -705,6 +645,12 @@ static int train_fused(wn_context* ctx, const double* X, int B, int lgR, int lgC
             WN_HIP(ctx, hipEventRecord(ctx->prof_end[ctx->prof_used], ctx->stream));
             ctx->prof_used++;
         }
+    }
+    if (in_kernel_tail) return WN_OK;
+    if (tail) {
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, ctx->stream, partial, grid, *tail);
+        WN_HIP(ctx, hipGetLastError());
+        return WN_OK;
     }
     hipLaunchKernelGGL(k_reduce_partials, dim3(ctx->N + 2), dim3(64), 0, ctx->stream, partial, grid, ctx->N, sums);
     WN_HIP(ctx, hipGetLastError());
@@ -803,14 +749,59 @@ int wn_get_sums(wn_context* ctx, double* sums_host, int* count) {
     return WN_OK;
 }
 
+static int update_params(wn_context* ctx, double batch_total, double lambda_sum, double alpha, double inertia_eff,
+                         int do_wavelet, wn::UpdateParams* P) {
+    if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
+    if (!(batch_total >= 1)) return fail(ctx, WN_ERR_ARG, "batch_total must be >= 1");
+    P->Bf = (double)(float)batch_total;  // the reference divides by float(size)
+    P->lambda_sum = lambda_sum;
+    P->alpha = alpha;
+    P->inertia_eff = inertia_eff;
+    P->wavelet = do_wavelet;
+    P->cap = kLogCap;
+    P->logF = ctx->log_filters;
+    P->logC = ctx->log_costs;
+    return WN_OK;
+}
+
 int wn_apply_update(wn_context* ctx, double batch_total, double lambda_sum, double alpha, double inertia_eff,
                     int do_wavelet) {
     if (!ctx) return WN_ERR_ARG;
-    if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
-    if (!(batch_total >= 1)) return fail(ctx, WN_ERR_ARG, "batch_total must be >= 1");
-    const double Bf = (double)(float)batch_total;  // the reference divides by float(size)
-    hipLaunchKernelGGL(k_update, dim3(1), dim3(64), 0, ctx->stream, ctx->dfilt, ctx->sums, Bf, lambda_sum, alpha,
-                       inertia_eff, do_wavelet, ctx->log_filters, ctx->log_costs, kLogCap);
+    wn::UpdateParams P;
+    const int rc = update_params(ctx, batch_total, lambda_sum, alpha, inertia_eff, do_wavelet, &P);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_update, dim3(1), dim3(64), 0, ctx->stream, ctx->dfilt, ctx->sums, P);
+    WN_HIP(ctx, hipGetLastError());
+    return WN_OK;
+}
+
+int wn_train_step(wn_context* ctx, const double* X, int B, int R, int C, double batch_total, double lambda_sum,
+                  double alpha, double inertia_eff, int do_wavelet) {
+    int lgR, lgC, sc;
+    int rc = check_shape(ctx, B, R, C, true, &lgR, &lgC, &sc);
+    if (rc) return rc;
+    if (B > 0 && !X) return fail(ctx, WN_ERR_ARG, "null input");
+    wn::UpdateParams P;
+    rc = update_params(ctx, batch_total, lambda_sum, alpha, inertia_eff, do_wavelet, &P);
+    if (rc) return rc;
+    const bool exchange = ctx->comm && ctx->nranks > 1;
+    if (sc >= 0) {
+        // one launch: the training kernel's last workgroup reduces the partial sums and, without a
+        // communicator, applies the update
+        wn::StepTail T;
+        T.ticket = ctx->ticket;
+        T.sums = ctx->sums;
+        T.filt = ctx->dfilt;
+        T.mode = exchange ? 1 : 2;
+        T.P = P;
+        rc = train_fused(ctx, X, B, lgR, lgC, sc, nullptr, nullptr, ctx->partial, ctx->partial_blocks, ctx->sums, &T);
+        if (rc || !exchange) return rc;
+    } else {
+        rc = wn_train_batch(ctx, X, B, R, C, nullptr, nullptr);
+        if (rc) return rc;
+    }
+    if (exchange && (rc = wn_allreduce_sums(ctx))) return rc;
+    hipLaunchKernelGGL(k_update, dim3(1), dim3(64), 0, ctx->stream, ctx->dfilt, ctx->sums, P);
     WN_HIP(ctx, hipGetLastError());
     return WN_OK;
 }

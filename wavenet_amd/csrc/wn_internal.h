@@ -31,6 +31,7 @@ struct wn_context {
     bool wave64 = true;  // 64x64 training on the one-wave-per-example kernel (WAVENET_HIP_WAVE64=0 turns it off)
     double* sums = nullptr;
     double* own_sums = nullptr;
+    unsigned* ticket = nullptr;  // counter of finished workgroups of a training kernel whose last workgroup ends the step
     std::vector<hipEvent_t> prof_begin, prof_end;
     int prof_used = 0;
     double* log_filters = nullptr;

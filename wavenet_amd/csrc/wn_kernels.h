@@ -4,6 +4,7 @@
 #pragma once
 
 #include "wn_device.h"
+#include "wn_step.h"
 
 namespace wn {
 
@@ -31,6 +32,7 @@ struct FusedArgs {
     double* grad;     // [B][N] sparsity gradient per example
     double* partial;  // [grid][PSTRIDE] per-workgroup sums: N gradient entries, S, non-finite count
     int F;            // cost grid only: number of filters in the table `filt` points to
+    StepTail tail;    // k_train64: what the last workgroup does with the partial sums (wn_step.h)
 };
 
 template <int T, int K>

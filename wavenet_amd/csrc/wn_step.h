@@ -1,0 +1,197 @@
+// The end of a training step inside the training kernel (k_train64: at most 1024 partial-sum slots, which one
+// workgroup adds up in a few microseconds): the workgroup that finishes last adds up the
+// per-wave partial sums and, on a single GPU, applies the filter update, so that a whole step
+// (src/Wavenet.cxx:184-242 for a batch, then flushBatchQueue_ / update_ / setFilter, :717-765, 8-36) is
+// ONE kernel launch and consecutive batches queue up on the stream with no host code in between.
+//
+// Hand-over between workgroups: every wave stores its slot write-through (agent-scope stores) and waits
+// for the stores to complete, the workgroup meets at a barrier, one lane takes a ticket from a device-wide
+// counter; the workgroup whose ticket is the last one acquires at agent scope and only then reads
+// the other workgroups' slots.  Nothing ever waits for another workgroup, so no placement or
+// residency assumption is made.
+#pragma once
+
+#include "wn_costfn.h"
+#include "wn_device.h"
+
+namespace wn {
+
+struct UpdateParams {
+    double Bf;            // float(batch size) as a double        (src/Wavenet.cxx:727, 733)
+    double lambda_sum;    // sum over the batch's examples of lambda
+    double alpha;
+    double inertia_eff;   // the caller's evaluation of src/Wavenet.cxx:757
+    int wavelet;
+    int cap;              // entries of the log rings
+    double* logF;         // [cap][MAXTAPS] filter after each update
+    double* logC;         // [cap] batch-mean cost of each update
+};
+
+struct StepTail {
+    unsigned* ticket;     // null: the kernel only writes its partial sums
+    double* sums;         // N + 2 sums of the batch
+    FilterDev* filt;      // the filter state to update (mode 2)
+    int mode;             // 1: sums only (the caller all-reduces them and updates), 2: sums and update
+    UpdateParams P;
+};
+
+struct UpdateShared {
+    double a[MAXTAPS], b[MAXTAPS], prefA[MAXTAPS + 1], prefB[MAXTAPS + 1], anew[MAXTAPS], pnew[MAXTAPS], cost;
+    float devA[MAXTAPS + 1], devB[MAXTAPS + 1];
+    int bad;
+};
+
+// LDS the tail needs at the start of the kernel's dynamic shared memory (every training kernel is done
+// with its own use of it by then)
+constexpr int TAIL_LDS_BYTES = 16 + (MAXTAPS + 2) * 8 + (int)sizeof(UpdateShared) + 16;
+
+__device__ inline void write_padded_filter(FilterDev* f, const double* a) {
+    const int N = f->N, d = f->d;
+    for (int j = 0; j < MAXTAPS; j++) { f->a[j] = 0; f->b[j] = 0; }
+    for (int j = 0; j < N; j++) {
+        f->a_true[j] = a[j];
+        f->a[j + d] = a[j];
+        f->b[j + d] = parity_sign(j) * a[N - 1 - j];
+    }
+}
+
+// Wavenet::flushBatchQueue_ / update_ / setFilter (src/Wavenet.cxx:717-765, 8-36) from the batch's sums.
+// Called by every thread of the workgroup (uniformly); threads 0..63 do the work: lane l evaluates lag
+// m = l - N/2 of the regularisation sums, lane i adds them up for tap i in the reference's order.
+// A batch whose sums, new filter or cost are not finite is not applied (the reference's train() fails
+// before anything is queued, src/Wavenet.cxx:234-241), and neither is any batch after it: the flag
+// stays up until the host takes it down.
+__device__ inline void update_body(FilterDev* f, const double* sums, const UpdateParams& P, UpdateShared& sh, int t) {
+    const int N = f->N;
+    if (t == 0) sh.bad = f->nonfinite;
+    __syncthreads();
+    if (t < 64) {
+        const bool bad_here = (t <= N && !isfinite(sums[t])) || (t == N + 1 && sums[t] != 0.0);
+        if (bad_here) sh.bad = 1;
+        if (t < N) sh.a[t] = f->a_true[t];
+    }
+    __syncthreads();
+    if (t < N) sh.b[t] = parity_sign(t) * sh.a[N - t - 1];
+    __syncthreads();
+    if (t <= N && !sh.bad) {
+        const int m = t - N / 2;
+        sh.prefA[t] = lag_prefactor(sh.a, N, m);
+        sh.devA[t] = lag_deviation_sq_float(sh.a, N, m);
+        sh.prefB[t] = lag_prefactor(sh.b, N, m);
+        sh.devB[t] = lag_deviation_sq_float(sh.b, N, m);
+    }
+    __syncthreads();
+    if (t < 64 && !sh.bad) {
+        const double suma = sum_taps(sh.a, N), sumb = sum_taps(sh.b, N);
+        if (t < N) {
+            double regd = 0;                                                            // RegTermDeriv, tap t
+            for (int l = 0; l <= N; l++) regd += sh.prefA[l] * lag_inner(sh.a, N, t, l - N / 2);
+            if (P.wavelet) {
+                regd += 2 * (suma - 1.4142135623730951) * 1.0;
+                for (int l = 0; l <= N; l++) regd += sh.prefB[l] * lag_inner(sh.a, N, t, l - N / 2);
+                regd += 2 * (sumb - 0) * parity_sign(N - t - 1);
+            }
+            double gbar = sums[t] + P.lambda_sum * regd;
+            gbar /= P.Bf;                                 // gradient /= float(size)          :727
+            double p = f->momentum[t] * P.inertia_eff;    // scaleMomentum_                    :760
+            p += -P.alpha * gbar;                         // addMomentum_                      :761
+            sh.pnew[t] = p;
+            sh.anew[t] = sh.a[t] + p;                     // setFilter(m_filter + m_momentum)  :762
+        }
+        if (t == 0) {
+            double reg = 0.;                                                            // RegTerm
+            float R2 = 0.f;
+            for (int l = 0; l <= N; l++) R2 = R2 + sh.devA[l];
+            reg += R2;
+            if (P.wavelet) {
+                const double c1 = suma - 1.4142135623730951;
+                reg += c1 * c1;
+                float R3 = 0.f;
+                for (int l = 0; l <= N; l++) R3 = R3 + sh.devB[l];
+                reg += R3;
+                reg += sumb * sumb;
+            }
+            reg = reg / 2.;
+            sh.cost = (sums[N] + P.lambda_sum * reg) / P.Bf;                            // :227, :733
+        }
+    }
+    __syncthreads();
+    // the same for a filter or a cost that overflowed on the way
+    if (!sh.bad && ((t < N && !isfinite(sh.anew[t])) || (t == 0 && !isfinite(sh.cost)))) sh.bad = 1;
+    __syncthreads();
+    if (sh.bad) {
+        if (t == 0) f->nonfinite = 1;
+        return;
+    }
+    if (t < N) f->momentum[t] = sh.pnew[t];
+    if (t == 0) {
+        const int idx = f->steps % P.cap;
+        P.logC[idx] = sh.cost;
+        f->steps = f->steps + 1;
+        for (int k = 0; k < MAXTAPS; k++) P.logF[(size_t)idx * MAXTAPS + k] = (k < N) ? sh.anew[k] : 0.0;
+        write_padded_filter(f, sh.anew);
+    }
+}
+
+// A partial sum leaves the workgroup write-through (an agent-scope store), so that the workgroup that ends the
+// step finds it in memory without anyone having to write a whole L2 back.
+__device__ __forceinline__ void store_partial(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Sum of quantity q over the partial-sum slots: lane l adds slots l, l + 64, ... in order, the 64 lane
+// sums are combined by a shuffle tree -- a fixed order, so the result does not depend on timing.  Lane 0
+// holds the result.
+__device__ __forceinline__ double reduce_slots(const double* partial, int nslots, int stride, int q, int lane) {
+    double s = 0;
+    // sixteen loads in flight at a time, added in slot order
+    for (int base = 0; base < nslots; base += 64 * 16) {
+        double v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int slot = base + 64 * i + lane;
+            v[i] = (slot < nslots) ? partial[(size_t)slot * stride + q] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (base + 64 * i + lane < nslots) s += v[i];
+        }
+    }
+    return wave_sum(s);
+}
+
+// Called by every thread of every workgroup of a training kernel after its partial sums have been stored
+// (store_partial).  T threads per workgroup; nslots slots of `stride` doubles in all; lds: the start of
+// the kernel's dynamic shared memory, at least TAIL_LDS_BYTES, 16-byte aligned, no longer in use.
+template <int T>
+__device__ __forceinline__ void step_tail(const StepTail& S, const double* partial, int nslots, int stride, void* lds, int tid) {
+    if (!S.ticket) return;   // the same in every thread of the launch
+    constexpr int NW = T / 64;
+    int* lastp = reinterpret_cast<int*>(lds);
+    double* ssum = reinterpret_cast<double*>(reinterpret_cast<char*>(lds) + 16);
+    UpdateShared& sh = *reinterpret_cast<UpdateShared*>(reinterpret_cast<char*>(lds) + 16 + (MAXTAPS + 2) * 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slot has left the wave
+    __syncthreads();                                    // ... and so has every other wave's of the workgroup
+    if (tid == 0) {
+        const unsigned mine = __hip_atomic_fetch_add(S.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int is_last = (mine == gridDim.x - 1u) ? 1 : 0;
+        if (is_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *lastp = is_last;
+    }
+    __syncthreads();
+    if (!*lastp) return;     // the same in every thread of the workgroup
+    const int N = S.filt->N;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int q = wave; q <= N + 1; q += NW) {
+        const double s = reduce_slots(partial, nslots, stride, q, lane);
+        if (lane == 0) { ssum[q] = s; S.sums[q] = s; }
+    }
+    if (tid == 0) __hip_atomic_store(S.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+    __syncthreads();
+    if (S.mode == 2) update_body(S.filt, ssum, S.P, sh, tid);
+}
+
+}  // namespace wn

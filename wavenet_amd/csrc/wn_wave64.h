@@ -727,8 +727,9 @@ __global__ __launch_bounds__(256, 1) void k_train64(FusedArgs A) {
     for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, 64);
     double* part = A.partial + (size_t)(blockIdx.x * 4 + wave) * PSTRIDE;
     const int k = lane - dpad;
-    if (lane < NP && k >= 0 && k < N) part[k] = accG;
-    if (lane == 0) { part[N] = accS; part[N + 1] = bad; }
+    if (lane < NP && k >= 0 && k < N) store_partial(part + k, accG);
+    if (lane == 0) { store_partial(part + N, accS); store_partial(part + N + 1, bad); }
+    step_tail<256>(A.tail, A.partial, (int)gridDim.x * 4, PSTRIDE, smem, (int)threadIdx.x);
 }
 
 }  // namespace wn

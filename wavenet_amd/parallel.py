@@ -49,6 +49,10 @@ class DataParallelTrainer:
         """One batch: B_local examples here, B_total over all ranks (default B_local * world_size)."""
         if B_total is None:
             B_total = B_local * self.world_size
+        if self.world_size == 1:
+            # one submission; up to 4096 samples per example one kernel launch (wn_train_step)
+            self.ctx.train_step(X_dev, B_local, R, C, B_total, lam * B_total, alpha, inertia_eff, wavelet)
+            return
         self.ctx.train_batch(X_dev, B_local, R, C)
         if self.world_size > 1:
             n = len_sums(self.ctx)
