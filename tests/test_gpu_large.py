@@ -1,4 +1,5 @@
-"""The streamed path (R*C > 4096: level-by-level kernels, segmented radix sort) against the CPU oracle,
+"""The streamed path (R*C > 4096: line and level kernels; Gini ranks by histogram + per-bucket LDS sort, or by
+device-wide radix sort with WAVENET_HIP_RANK=radix and whenever a bucket would overflow) against the CPU oracle,
 including the full sizes of the 512x512 and 2^20-sample configurations."""
 import numpy as np
 import pytest
@@ -14,6 +15,31 @@ def ctx():
     import torch
     from wavenet_amd import Context
     c = Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    yield c
+    torch.cuda.synchronize()
+    c.close()
+
+
+def _ctx_with_env(name, value):
+    import os
+    import torch
+    from wavenet_amd import Context
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        return Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    finally:
+        if old is None:
+            del os.environ[name]
+        else:
+            os.environ[name] = old
+
+
+@pytest.fixture(scope="module", params=["buckets", "radix"])
+def ctx_rank(request):
+    """A context per ranking method of the streamed path."""
+    import torch
+    c = _ctx_with_env("WAVENET_HIP_RANK", request.param)
     yield c
     torch.cuda.synchronize()
     c.close()
@@ -133,23 +159,8 @@ def test_full_size_properties_512(ctx):
     assert torch.allclose(ex, ey, rtol=1e-9)
 
 
-def _ctx_with_env(name, value):
-    import os
-    import torch
-    from wavenet_amd import Context
-    old = os.environ.get(name)
-    os.environ[name] = value
-    try:
-        return Context(0, stream=torch.cuda.current_stream().cuda_stream)
-    finally:
-        if old is None:
-            del os.environ[name]
-        else:
-            os.environ[name] = old
-
-
 @pytest.mark.parametrize("n,B", [(8192, 5), (65536, 3), (1 << 18, 2)])
-def test_sparse_term_32bit_keys_against_64bit_sort(ctx, oracle, n, B):
+def test_sparse_term_32bit_keys_against_64bit_sort(ctx_rank, oracle, n, B):
     """The streamed Gini ranks with one sort of 32-bit keys (example number, leading magnitude bits) and
     re-ranks groups of equal keys by exact magnitude and index.  Inputs: smooth random values (small
     groups everywhere), zeros, and pairs that differ only in their last mantissa bits and stand in the
@@ -164,7 +175,7 @@ def test_sparse_term_32bit_keys_against_64bit_sort(ctx, oracle, n, B):
     Y[B - 1, 5::11] = Y[B - 1, 3::11][:len(Y[B - 1, 5::11])]   # exact ties
     dY = torch.from_numpy(Y.reshape(-1)).cuda()
     dD, dS = dev_empty(B * n), dev_empty(B)
-    ctx.sparse_term_deriv(dY, B, n, dD, dS)
+    ctx_rank.sparse_term_deriv(dY, B, n, dD, dS)
     torch.cuda.synchronize()
     D, S = dD.cpu().numpy().reshape(B, n), dS.cpu().numpy()
     exact = _ctx_with_env("WAVENET_HIP_EXACT_SORT", "1")
@@ -184,7 +195,7 @@ def test_sparse_term_32bit_keys_against_64bit_sort(ctx, oracle, n, B):
 
 @pytest.mark.parametrize("n", [8192, 1 << 18])
 @pytest.mark.parametrize("in_place", [False, True])
-def test_sparse_term_zeros_left_out_of_the_sort(ctx, oracle, n, in_place):
+def test_sparse_term_zeros_left_out_of_the_sort(ctx_rank, oracle, n, in_place):
     """Exact zeros are compacted away before the sort and rank first: an all-zero example (NaN cost, as in
     the reference), a mostly-zero one with its non-zeros at workgroup boundaries, a dense one, a single
     non-zero coefficient, and signed zeros; errors written in place and to a separate array."""
@@ -200,7 +211,7 @@ def test_sparse_term_zeros_left_out_of_the_sort(ctx, oracle, n, in_place):
     dY = torch.from_numpy(Y.reshape(-1).copy()).cuda()
     dD = dY if in_place else dev_empty(B * n).fill_(7.0)
     dS = dev_empty(B)
-    ctx.sparse_term_deriv(dY, B, n, dD, dS)
+    ctx_rank.sparse_term_deriv(dY, B, n, dD, dS)
     torch.cuda.synchronize()
     D = dD.cpu().numpy().reshape(B, n)
     S = dS.cpu().numpy()
@@ -214,7 +225,7 @@ def test_sparse_term_zeros_left_out_of_the_sort(ctx, oracle, n, in_place):
 
 
 @pytest.mark.parametrize("n", [8192, 1 << 18])
-def test_sparse_term_magnitudes_outside_the_key_range(ctx, oracle, n):
+def test_sparse_term_magnitudes_outside_the_key_range(ctx_rank, oracle, n):
     """The sort key keeps 7 exponent bits (2^-95 ... 2^33) and the leading mantissa bits; smaller and larger
     magnitudes share the end keys and are ordered by the exact re-ranking of equal keys, as are the
     several coefficients per key of a dense example."""
@@ -228,7 +239,7 @@ def test_sparse_term_magnitudes_outside_the_key_range(ctx, oracle, n):
     Y[2] = 1.0 + rng.random(n) * 2.0 ** -8               # one binade, many per key
     dY = torch.from_numpy(Y.reshape(-1)).cuda()
     dD, dS = dev_empty(B * n), dev_empty(B)
-    ctx.sparse_term_deriv(dY, B, n, dD, dS)
+    ctx_rank.sparse_term_deriv(dY, B, n, dD, dS)
     torch.cuda.synchronize()
     D, S = dD.cpu().numpy().reshape(B, n), dS.cpu().numpy()
     for e in range(B):
@@ -308,3 +319,62 @@ def test_line_kernels_against_level_kernels(ctx, R, C, N):
     assert relerr(dG.cpu().numpy(), dG2.cpu().numpy()) < 1e-11
     assert np.abs(dS.cpu().numpy() / dS2.cpu().numpy() - 1).max() < 1e-12
     assert relerr(sums[:N + 1], sums2[:N + 1]) < 1e-11 and sums[N + 1] == sums2[N + 1] == 0
+
+
+def _capture_ranking(ctx, capfd, dY, B, n):
+    """sparse_term_deriv with the library's remarks on; returns (D, S, gave_up)."""
+    import os
+    import torch
+    dD, dS = dev_empty(B * n), dev_empty(B)
+    capfd.readouterr()
+    ctx.sparse_term_deriv(dY, B, n, dD, dS)
+    torch.cuda.synchronize()
+    err = capfd.readouterr().err
+    return dD.cpu().numpy().reshape(B, n), dS.cpu().numpy(), "bucket ranking gave up" in err
+
+
+@pytest.mark.parametrize("n,B", [(8192, 700), (16384, 3), (65536, 9), (1 << 18, 3), (1 << 20, 2), (1 << 21, 1)])
+def test_bucket_ranking(oracle, capfd, monkeypatch, n, B):
+    """Ranks by histogram and per-bucket LDS sort (wn_rank.h) against the oracle and against the radix-sort path:
+    many examples (one workgroup per example in the histogram and partition kernels) and few (several workgroups
+    per example, cursors in global memory); stragglers hundreds of octaves below the rest (the lowest bin collects
+    what lies 32 octaves below the largest; in long examples its bucket sorts magnitudes and indices side by side); zeros;
+    exact ties and near-ties in the opposite order of their indices; a constant-magnitude example that overflows
+    every bucket and must take the radix path, alone in its chunk."""
+    import torch
+    monkeypatch.setenv("WAVENET_HIP_VERBOSE", "1")
+    rng = np.random.default_rng(n + B)
+    Y = rng.standard_normal((B, n)) * np.exp(rng.standard_normal((B, n)))
+    Y[0, ::5] = 0.0
+    if B > 1:
+        Y[1] = rng.standard_normal(n) * 2.0 ** rng.integers(-20, 1, size=n)
+        far = rng.choice(n, size=1500, replace=False)                                # stragglers hundreds of octaves below
+        Y[1, far] = rng.standard_normal(1500) * 2.0 ** rng.integers(-440, -40, size=1500)
+    last = B - 1
+    m = min(n // 8, 8192)
+    base = 1.0 + rng.random(m)
+    Y[last, 0:m] = base * (1 + 2.0 ** -50)
+    Y[last, n // 2:n // 2 + m] = -base
+    Y[last, 5::11] = Y[last, 3::11][:len(Y[last, 5::11])]
+    dY = torch.from_numpy(Y.reshape(-1)).cuda()
+    buckets = _ctx_with_env("WAVENET_HIP_RANK", "buckets")
+    radix = _ctx_with_env("WAVENET_HIP_RANK", "radix")
+    try:
+        D, S, gave_up = _capture_ranking(buckets, capfd, dY, B, n)
+        assert not gave_up
+        D2, S2, _ = _capture_ranking(radix, capfd, dY, B, n)
+        assert np.abs(S - S2).max() < 1e-13
+        for e in sorted({0, 1 % B, last, B // 2}):
+            assert relerr(D[e], D2[e]) < 1e-11
+            assert S[e] == pytest.approx(oracle.sparse_term(Y[e]), rel=1e-11)
+            assert relerr(D[e], oracle.sparse_term_deriv(Y[e])) < 1e-9
+        # every magnitude one of five values: each bin holds a fifth of the example
+        ties = np.where(rng.random(n) < 0.5, 0.5, -0.5) * (1 + (np.arange(n) % 5))
+        dT = torch.from_numpy(ties).cuda()
+        Dt, St, gave_up = _capture_ranking(buckets, capfd, dT, 1, n)
+        assert gave_up == (n >= 32768)     # 3277 equal magnitudes still fit a bucket, 6554 do not
+        assert St[0] == pytest.approx(oracle.sparse_term(ties), rel=1e-11)
+        assert relerr(Dt[0], oracle.sparse_term_deriv(ties)) < 1e-9
+    finally:
+        buckets.close()
+        radix.close()

@@ -7,6 +7,8 @@
 //
 // Reference stages: forward_ (src/Wavenet.cxx:404-445, 562-622), SparseTerm(Deriv)
 // (src/CostFunctions.cxx:6-117), backpropagate_ (src/Wavenet.cxx:474-556, 665-711).
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -15,6 +17,7 @@
 #include <vector>
 
 #include "wn_internal.h"
+#include "wn_rank.h"
 
 extern "C" const void* wn_kernel_lines_np2(int kind, int M);
 extern "C" const void* wn_kernel_lines_np4(int kind, int M);
@@ -872,11 +875,70 @@ int gini_big(wn_context* ctx, const double* Y, double* D, int B, size_t n, doubl
     return WN_OK;
 }
 
+// Ranks by histogram and per-bucket LDS sort (wn_rank.h).  Leaves 32-bit ranks at home positions in keysB
+// (example e at (unsigned*)keysB + e * n), {f, g} in fg, the sparsity terms in S_e, and with D the errors.
+// *ok = false: some bucket would overflow (or the example is too long) -- nothing usable was written.
+// kmax: B words; kmax_ready: the producer of Y has raised them already.
+int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB, unsigned* idxA,
+                 unsigned* idxB, double* fg, double* S_e, unsigned* kmax, bool kmax_ready, bool* ok) {
+    using namespace rk;
+    *ok = false;
+    int lgn = 0;
+    while (((size_t)1 << lgn) < n) lgn++;
+    if (lgn > RK_LGN_MAX || n < 8192) return WN_OK;
+    hipStream_t st = ctx->stream;
+    const int NF = (int)std::min<size_t>(RK_NFMAX, std::max<size_t>(1024, n / 2));
+    int lgBPO = 0;
+    while ((RK_OCTAVES << lgBPO) < NF) lgBPO++;   // bins per octave: NF / RK_OCTAVES
+    const int nbmax = nbmax_for(n);
+    unsigned* hist = idxB;                                                           // B * NF words
+    unsigned short* btab = reinterpret_cast<unsigned short*>(idxB + (size_t)B * NF);  // B * NF half words
+    unsigned* rank = reinterpret_cast<unsigned*>(keysB);                              // B * n words
+    unsigned* meta = rank + (size_t)B * n;                                            // B * meta_words(n) words
+    unsigned* flag = meta + (size_t)B * meta_words(n);
+    unsigned long long* mag = reinterpret_cast<unsigned long long*>(keysA);
+    static bool configured = false;
+    if (!configured) {
+        WN_HIP(ctx, hipFuncSetAttribute((const void*)kr_hist, hipFuncAttributeMaxDynamicSharedMemorySize, RK_NFMAX * 4));
+        WN_HIP(ctx, hipFuncSetAttribute((const void*)kr_scan, hipFuncAttributeMaxDynamicSharedMemorySize, RK_NFMAX * 4));
+        WN_HIP(ctx, hipFuncSetAttribute((const void*)kr_part<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RK_NFMAX * 2));
+        WN_HIP(ctx, hipFuncSetAttribute((const void*)kr_part<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RK_NFMAX * 2));
+        configured = true;
+    }
+    // workgroups per example: enough of them to fill the chip when the chunk has few examples
+    int G = 1;
+    while ((long long)G * B < 2LL * ctx->numCU && n / (2 * (size_t)G) >= (size_t)RK_TILE) G *= 2;
+    if (!kmax_ready) {
+        WN_HIP(ctx, hipMemsetAsync(kmax, 0, (size_t)B * sizeof(unsigned), st));
+        hipLaunchKernelGGL(kr_max, dim3(G, B), dim3(RK_PT), 0, st, Y, n, kmax);
+    }
+    if (G > 1) WN_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)B * NF * sizeof(unsigned), st));
+    WN_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(kr_hist, dim3(G, B), dim3(RK_PT), (size_t)NF * 4, st, Y, n, kmax, hist, NF, lgBPO);
+    hipLaunchKernelGGL(kr_scan, dim3(B), dim3(RK_BT), (size_t)NF * 4, st, hist, kmax, NF, lgBPO, n, btab, meta, flag);
+    if (G == 1) hipLaunchKernelGGL(kr_part<true>, dim3(1, B), dim3(RK_PT), (size_t)NF * 2, st, Y, n, btab, meta, NF, lgBPO, mag, idxA, flag);
+    else hipLaunchKernelGGL(kr_part<false>, dim3(G, B), dim3(RK_PT), (size_t)NF * 2, st, Y, n, btab, meta, NF, lgBPO, mag, idxA, flag);
+    hipLaunchKernelGGL(kr_bucket, dim3((unsigned)nbmax * (((unsigned)B + 7u) & ~7u)), dim3(RK_KT), 0, st, mag, idxA, n, meta, rank, B, flag, NF, lgBPO);
+    hipLaunchKernelGGL(kr_finish, dim3((B + BT - 1) / BT), dim3(BT), 0, st, meta, n, B, fg, S_e);
+    WN_HIP(ctx, hipGetLastError());
+    unsigned over = 0;
+    WN_HIP(ctx, hipMemcpyAsync(&over, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    WN_HIP(ctx, hipStreamSynchronize(st));
+    if (over) return WN_OK;
+    if (D) {
+        hipLaunchKernelGGL(kb_delta_home, grid_for((int)std::min<size_t>(n, 1u << 30), B), dim3(BT), 0, st, Y, rank, D, fg, (unsigned)n);
+        WN_HIP(ctx, hipGetLastError());
+    }
+    *ok = true;
+    return WN_OK;
+}
+
 // Gini term and gradient of a chunk: the short-key path when it applies, else gini_big.  The chunk is
 // sorted in slices of at most 2^23 coefficients (32 examples of 512x512, 8 signals of 2^20 samples).
 int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB,
                unsigned* idxA, unsigned* idxB, unsigned* cnt, double* gpart, double* fg, double* S_e, void* sort_tmp,
-               size_t sort_tmp_bytes, int* rank_slice = nullptr, bool counts_ready = false) {
+               size_t sort_tmp_bytes, int* rank_slice = nullptr, bool counts_ready = false, unsigned* kmax = nullptr,
+               bool kmax_ready = false) {
     // rank_slice (with D null): receives the number of examples per slice when the ranks were left in keysB
     // (slice s at keysB + s * slice * n, as 32-bit ranks at home positions) for a consumer that computes
     // the errors itself, 0 when this path did not apply and only the sums were computed.
@@ -884,6 +946,18 @@ int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, dou
     if (rank_slice) *rank_slice = 0;
     int lgn = 0;
     while (((size_t)1 << lgn) < n) lgn++;
+    if (ctx->bucket_rank && !ctx->exact_sort && kmax) {
+        bool ok = false;
+        const int rc = gini_buckets(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, fg, S_e, kmax, kmax_ready, &ok);
+        if (rc) return rc;
+        if (ok) {
+            if (rank_slice) *rank_slice = B;   // one slice: example e's ranks at (unsigned*)keysB + e * n
+            return WN_OK;
+        }
+        counts_ready = false;   // the caller skipped the non-zero counts this path does not need
+        const bool verbose = getenv("WAVENET_HIP_VERBOSE") != nullptr;
+        if (verbose) fprintf(stderr, "wavenet_hip: bucket ranking gave up on a chunk of %d examples of %zu coefficients, radix sort instead\n", B, n);
+    }
     const int exbits_max = 26 - lgn;   // slices of 2^26 coefficients
     if (exbits_max < 0 || ctx->exact_sort)
         return gini_big(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, gpart, fg, S_e, sort_tmp, sort_tmp_bytes);
@@ -951,7 +1025,7 @@ struct Plan {
     int Bc;                 // examples per chunk
     size_t n;
     double *Prow, *Y1, *Pcol, *YD, *A, *Bb, *gpart, *fg, *partial, *grad_e, *S_e;
-    unsigned *idxA, *idxB, *cnt;
+    unsigned *idxA, *idxB, *cnt, *kmax;
     void* sort_tmp;
     size_t sort_tmp_bytes;
 };
@@ -977,6 +1051,7 @@ int make_plan(wn_context* ctx, int B, size_t n, int NP, int N, Plan* pl) {
         pl->idxA = c.take<unsigned>(Bc * n);
         pl->idxB = c.take<unsigned>(Bc * n);
         pl->cnt = c.take<unsigned>(Bc * (n / CP_BLOCK + 1) + 3 * Bc + 64);
+        pl->kmax = c.take<unsigned>(Bc + 16);
         pl->gpart = c.take<double>(Bc * GXMAX * 2);
         pl->fg = c.take<double>(Bc * 2);
         pl->partial = c.take<double>(Bc * GXMAX * 2 * NP);
@@ -1023,6 +1098,7 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         const int Mrow = C / 64, Mcol = R / 64;     // samples per lane
         const bool rowLines = (NP <= 8 && lgC >= 7 && lgC <= 10 && R >= line_tile_rows(Mrow) && ctx->wave64 && !ProwOut);
         const bool colLines = ((NP <= 8 || (NP == 16 && (lgR == 8 || lgR == 9))) && lgR >= 7 && lgR <= 10 && lgC > 0 && ctx->wave64);
+        const bool buckets = ctx->bucket_rank && !ctx->exact_sort && (lgR + lgC) <= rk::RK_LGN_MAX;
         const double* Yc = YD;
         double* pcolArg = PcolOut ? Pcol : nullptr;
         size_t xs = n;
@@ -1043,9 +1119,12 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         if (colLines) {
             const double* y1c = Y1;
             // the Gini phase's first step rides along: non-zero counts per CP_BLOCK coefficients
-            unsigned* counts = forward_only ? nullptr : pl.cnt;
+            // (bucket ranking: the largest exponent word per example; radix ranking: the non-zero counts)
+            unsigned* counts = (forward_only || buckets) ? nullptr : pl.cnt;
+            unsigned* kmaxArg = (!forward_only && buckets) ? pl.kmax : nullptr;
             if (counts) WN_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)Bc * (n / CP_BLOCK) * sizeof(unsigned), st));
-            void* args[] = {(void*)&y1c, (void*)&YD, (void*)&pcolArg, (void*)&xs, (void*)&ncols, (void*)&dfilt, (void*)&counts};
+            if (kmaxArg) WN_HIP(ctx, hipMemsetAsync(kmaxArg, 0, (size_t)Bc * sizeof(unsigned), st));
+            void* args[] = {(void*)&y1c, (void*)&YD, (void*)&pcolArg, (void*)&xs, (void*)&ncols, (void*)&dfilt, (void*)&counts, (void*)&kmaxArg};
             WN_HIP(ctx, hipLaunchKernel(line_kernel(NP, LN_FWD_COLS, Mcol), dim3(std::min(C, LN_GX), Bc), dim3(64), args, 0, st));
         } else if ((rc = fwd_pass_big<NP>(ctx, Y1, Pcol, YD, Bc, n, cg))) {
             return rc;
@@ -1057,10 +1136,11 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         // the ranks; otherwise (or when the short-key ranking did not apply) they replace the coefficients in YD
         int rank_slice = 0;
         if (colLines && (rc = gini_large(ctx, YD, nullptr, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp,
-                                         pl.sort_tmp_bytes, &rank_slice, true)))
+                                         pl.sort_tmp_bytes, &rank_slice, !buckets, pl.kmax, buckets)))
             return rc;
         if (!rank_slice &&
-            (rc = gini_large(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes)))
+            (rc = gini_large(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes,
+                             nullptr, false, pl.kmax, false)))
             return rc;
         WN_HIP(ctx, hipMemsetAsync(pl.partial, 0, (size_t)Bc * GXMAX * 2 * NP * sizeof(double), st));
         const double* D1 = nullptr;
@@ -1182,7 +1262,7 @@ int large_sparse(wn_context* ctx, const double* Y, int B, long long n, double* D
         const int Bc = std::min(pl.Bc, B - e0);
         const size_t o = (size_t)e0 * n;
         if ((rc = gini_large(ctx, Y + o, Delta ? Delta + o : nullptr, Bc, (size_t)n, pl.A, pl.Bb, pl.idxA, pl.idxB,
-                           pl.cnt, pl.gpart, pl.fg, S ? S + e0 : nullptr, pl.sort_tmp, pl.sort_tmp_bytes)))
+                           pl.cnt, pl.gpart, pl.fg, S ? S + e0 : nullptr, pl.sort_tmp, pl.sort_tmp_bytes, nullptr, false, pl.kmax, false)))
             return rc;
     }
     return WN_OK;

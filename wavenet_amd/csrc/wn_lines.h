@@ -160,14 +160,16 @@ struct LineGini {
 // grid (workgroups per example, examples), 64 threads.  in/Y/P: chunk arrays, example stride xs, column c
 // of an example at c * 64 M.  P may be null.  counts (may be null): counts[i] receives (is added) the number
 // of non-zero coefficients among the chunk's coefficients [2048 i, 2048 (i + 1)) -- what the streamed Gini
-// phase needs first, gathered while the coefficients are still in registers.
+// phase needs first, gathered while the coefficients are still in registers.  kmax (may be null): kmax[example]
+// is raised to the largest exponent word among the example's coefficients.
 template <int NP, int M>
 __global__ LN_BOUNDS(64) void kc_fwd_cols(const double* __restrict__ in, double* __restrict__ Y, double* __restrict__ P, size_t xs,
-                                          int ncols, const FilterDev* filt, unsigned* counts) {
+                                          int ncols, const FilterDev* filt, unsigned* counts, unsigned* kmax) {
     const int lane = threadIdx.x;
     double a[NP], b[NP];
     ln_load_taps<NP>(filt, a, b);
     const size_t off = (size_t)blockIdx.y * xs;
+    unsigned kmine = 0;
     for (int c = blockIdx.x; c < ncols; c += gridDim.x) {
         const size_t lo = off + (size_t)c * (64 * M);
         LinePyramid<M> p;
@@ -183,6 +185,15 @@ __global__ LN_BOUNDS(64) void kc_fwd_cols(const double* __restrict__ in, double*
             for (int k = 0; k < M; k++) nz += (unsigned)__popcll(__ballot(y.v[k] != 0.0));
             if (lane == 0) atomicAdd(&counts[lo / 2048], nz);
         }
+        if (kmax) {   // the largest exponent word (upper half of |c|) so far, for the ranking's histogram
+#pragma unroll
+            for (int k = 0; k < M; k++) kmine = max(kmine, (unsigned)__double2hiint(y.v[k]) & 0x7FFFFFFFu);
+        }
+    }
+    if (kmax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kmine = max(kmine, (unsigned)__shfl_xor((int)kmine, o, 64));
+        if (lane == 0 && kmine) atomicMax(&kmax[blockIdx.y], kmine);
     }
 }
 

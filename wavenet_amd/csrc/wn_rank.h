@@ -1,0 +1,498 @@
+// Gini ranks of examples beyond 4096 coefficients without a device-wide sort (src/CostFunctions.cxx:67-102:
+// the rank of |c_j| among the example's magnitudes, ties in index order).
+//
+// A full sort moves every (key, position) pair through memory once per radix pass.  Here the only thing
+// ever sorted is a bucket of at most 4096 magnitudes, in LDS:
+//   1. kr_hist   per example a histogram of the non-zero magnitudes over NF logarithmic bins (bins per octave
+//                fixed, counted down from the example's largest magnitude, whose exponent word the producer
+//                of the coefficients left in kmax), built in LDS;
+//   2. kr_scan   prefix sums of the histogram; consecutive bins are grouped into buckets by cutting the sorted
+//                order every RK_T positions (bucket of a bin = its first sorted position / RK_T), so a bucket
+//                holds fewer than RK_T + (largest bin) magnitudes;
+//   3. kr_part   every non-zero magnitude, with its home index, goes to its bucket's range of a staging array
+//                (order inside the bucket: as it comes);
+//   4. kr_bucket one workgroup per bucket: a counting sort in LDS over 4096 sub-bins that split the bucket's
+//                own magnitude range linearly, exact (magnitude, index) comparison inside a sub-bin, the rank
+//                written to the coefficient's home position, and the bucket's share of the two Gini sums from
+//                the magnitudes in sorted order;
+//   5. kr_finish adds the buckets' shares per example in bucket order.
+// Exact zeros are left out (they rank first and need no rank of their own).  Every rank is decided by exact
+// comparisons, so the result does not depend on the order in which atomics land; every sum is taken in a fixed
+// order.  A bucket that would hold more than RK_CAP magnitudes (thousands of coefficients within half a percent
+// of each other, or equal) raises a flag and the caller falls back to the radix-sort path.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wn_device.h"
+
+namespace wn {
+namespace rk {
+
+constexpr int RK_T = 3072;       // sorted positions per bucket
+constexpr int RK_CAP = 4096;     // magnitudes a bucket may hold
+constexpr int RK_NFMAX = 16384;  // histogram bins at most (512 per octave over RK_OCTAVES octaves)
+constexpr int RK_OCTAVES = 32;   // octaves below the largest magnitude that get bins of their own; what lies below shares the lowest bin
+constexpr int RK_TILE = 2048;    // coefficients per step of kr_part
+constexpr int RK_PT = 512;       // threads of kr_hist / kr_part
+constexpr int RK_BT = 1024;      // threads of kr_scan
+constexpr int RK_KT = 512;       // threads of kr_bucket
+constexpr int RK_KE = 8;         // magnitudes (and sub-bins) per thread of kr_bucket
+constexpr int RK_NSB = 4096;     // sub-bins of a bucket
+constexpr int RK_NBMAX = 1024;   // buckets per example at most: examples of up to 2^21 coefficients
+constexpr int RK_LGN_MAX = 21;
+
+// Workgroup barrier for hand-overs through LDS only: waits for this wave's LDS operations, not for its global
+// loads and stores (__syncthreads() also drains those, which would put the memory latency of every prefetch and
+// every scattered store on the critical path of each step).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__host__ __device__ inline int nbmax_for(size_t n) { return (int)(n / RK_T) + 2; }
+// per example: u32 words {nz, nb, Lmax, kmax, bstart[nbmax + 1], binfirst[nbmax + 1], cursor[nbmax]}, then doubles bpart[2 nbmax]
+__host__ __device__ inline size_t meta_words(size_t n) {
+    const size_t nb = (size_t)nbmax_for(n);
+    return ((4 + 2 * (nb + 1) + nb + 1) & ~(size_t)1) + 4 * nb;
+}
+__device__ __forceinline__ unsigned* meta_bstart(unsigned* m) { return m + 4; }
+__device__ __forceinline__ unsigned* meta_binfirst(unsigned* m, int nbmax) { return m + 4 + nbmax + 1; }
+__device__ __forceinline__ unsigned* meta_cursor(unsigned* m, int nbmax) { return m + 4 + 2 * (nbmax + 1); }
+__device__ __forceinline__ double* meta_bpart(unsigned* m, int nbmax) {
+    return reinterpret_cast<double*>(m + ((4 + 2 * (nbmax + 1) + nbmax + 1) & ~1));
+}
+// The magnitudes (bit patterns) that fall into bins [f0, f1] lie in [*lo, *hi].
+__device__ __forceinline__ void bin_range(unsigned f0, unsigned f1, unsigned Lmax, unsigned kmax, int lgBPO, int NF,
+                                          unsigned long long* lo, unsigned long long* hi) {
+    const int shift = 20 - lgBPO;
+    const unsigned d0 = (unsigned)(NF - 1) - f0, d1 = (unsigned)(NF - 1) - f1;
+    const unsigned k0 = (f0 == 0 || d0 > Lmax) ? 0u : (Lmax - d0) << shift;                    // the lowest bin takes all that is smaller
+    const unsigned k1 = (d1 == 0 || d1 > Lmax) ? kmax : (((Lmax - d1) + 1u) << shift) - 1u;  // the highest bin ends at the maximum
+    *lo = (unsigned long long)k0 << 32;
+    *hi = ((unsigned long long)k1 << 32) | 0xFFFFFFFFull;
+}
+
+// histogram bin of a magnitude's exponent word (the upper 32 bits of |c|): lgBPO = log2(bins per octave)
+__device__ __forceinline__ unsigned fine_bin(unsigned key32, unsigned Lmax, int lgBPO, int NF) {
+    const unsigned L = key32 >> (20 - lgBPO);
+    const unsigned d = (L > Lmax) ? 0u : Lmax - L;
+    return (unsigned)(NF - 1) - (d < (unsigned)(NF - 1) ? d : (unsigned)(NF - 1));
+}
+
+// kmax[e] = largest exponent word among the example's coefficients; grid (G, B).  Used when the kernel that
+// produced the coefficients did not leave it.
+__global__ __launch_bounds__(RK_PT) void kr_max(const double* __restrict__ Y, size_t n, unsigned* kmax) {
+    const size_t per = n / gridDim.x;
+    const double* src = Y + (size_t)blockIdx.y * n + (size_t)blockIdx.x * per;
+    unsigned m = 0;
+    for (size_t i = 2 * threadIdx.x; i < per; i += 2 * RK_PT) {
+        const double2 v = *reinterpret_cast<const double2*>(src + i);
+        const unsigned k0 = (unsigned)__double2hiint(v.x) & 0x7FFFFFFFu, k1 = (unsigned)__double2hiint(v.y) & 0x7FFFFFFFu;
+        m = max(m, max(k0, k1));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(&kmax[blockIdx.y], m);
+}
+
+// hist[e][f] (+)= number of non-zero coefficients of example e in bin f; grid (G, B), NF * 4 bytes of LDS.
+// G == 1: plain stores of every bin; else hist must be zero beforehand and the workgroups add.
+__global__ __launch_bounds__(RK_PT) void kr_hist(const double* __restrict__ Y, size_t n, const unsigned* __restrict__ kmax,
+                                                 unsigned* hist, int NF, int lgBPO) {
+    extern __shared__ unsigned rk_h[];
+    const int e = blockIdx.y;
+    for (int f = threadIdx.x; f < NF; f += RK_PT) rk_h[f] = 0;
+    __syncthreads();
+    const unsigned Lmax = kmax[e] >> (20 - lgBPO);
+    const size_t per = n / gridDim.x;
+    const double* src = Y + (size_t)e * n + (size_t)blockIdx.x * per;
+    for (size_t i0 = 0; i0 < per; i0 += 8 * RK_PT) {
+        double2 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const size_t i = i0 + 2 * (size_t)(k * RK_PT + threadIdx.x);
+            v[k] = (i < per) ? *reinterpret_cast<const double2*>(src + i) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (v[k].x != 0.0) atomicAdd(&rk_h[fine_bin((unsigned)__double2hiint(v[k].x) & 0x7FFFFFFFu, Lmax, lgBPO, NF)], 1u);
+            if (v[k].y != 0.0) atomicAdd(&rk_h[fine_bin((unsigned)__double2hiint(v[k].y) & 0x7FFFFFFFu, Lmax, lgBPO, NF)], 1u);
+        }
+    }
+    __syncthreads();
+    unsigned* out = hist + (size_t)e * NF;
+    if (gridDim.x == 1) {
+        for (int f = threadIdx.x; f < NF; f += RK_PT) out[f] = rk_h[f];
+    } else {
+        for (int f = threadIdx.x; f < NF; f += RK_PT) {
+            const unsigned c = rk_h[f];
+            if (c) atomicAdd(&out[f], c);
+        }
+    }
+}
+
+// Exclusive prefix sum over the workgroup of one value per thread (T threads); *total receives the sum.
+template <int T = RK_BT>
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned* wsum /* T / 64 + 1 */, unsigned* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = (unsigned)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    lds_barrier();
+    if (lane == 63) wsum[wave] = incl;
+    lds_barrier();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int w = 0; w < T / 64; w++) { const unsigned c = wsum[w]; wsum[w] = run; run += c; }
+        wsum[T / 64] = run;
+    }
+    lds_barrier();
+    if (total) *total = wsum[T / 64];
+    return wsum[wave] + incl - v;
+}
+
+// Per example: bins -> buckets.  btab[e][f] = bucket of bin f; meta: counts, bucket starts, cursors zeroed.
+// grid (B), RK_BT threads, NF * 4 bytes of dynamic LDS.
+__global__ __launch_bounds__(RK_BT) void kr_scan(const unsigned* __restrict__ hist, const unsigned* __restrict__ kmax, int NF, int lgBPO,
+                                                 size_t n, unsigned short* btab, unsigned* meta_all, unsigned* flag) {
+    extern __shared__ unsigned rk_c[];            // cum[NF]
+    __shared__ unsigned wsum[RK_BT / 64 + 1];
+    __shared__ unsigned bs[RK_NBMAX], bf0[RK_NBMAX];   // bucket starts and first bins: nbmax + 1 = n / RK_T + 3 entries
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const int nbmax = nbmax_for(n);
+    unsigned* meta = meta_all + (size_t)e * meta_words(n);
+    const unsigned* h = hist + (size_t)e * NF;
+    const int per = NF / RK_BT;                   // consecutive bins per thread (NF is a multiple of RK_BT)
+    unsigned loc[RK_NFMAX / RK_BT];
+    unsigned sum = 0;
+#pragma unroll
+    for (int k = 0; k < RK_NFMAX / RK_BT; k++) {
+        loc[k] = (k < per) ? h[tid * per + k] : 0u;
+        sum += loc[k];
+    }
+    unsigned nz;
+    unsigned run = block_exclusive_scan(sum, wsum, &nz);
+#pragma unroll
+    for (int k = 0; k < RK_NFMAX / RK_BT; k++) {
+        if (k < per) { rk_c[tid * per + k] = run; run += loc[k]; }
+    }
+    for (int b = tid; b <= nbmax; b += RK_BT) { bs[b] = nz; bf0[b] = (unsigned)NF; }
+    __syncthreads();
+    unsigned short* bt = btab + (size_t)e * NF;
+    for (int f = tid; f < NF; f += RK_BT) {
+        const int bf = (int)(rk_c[f] / RK_T);
+        const int bprev = f ? (int)(rk_c[f - 1] / RK_T) : -1;
+        for (int b = bprev + 1; b <= bf; b++) { bs[b] = rk_c[f]; bf0[b] = (unsigned)f; }   // the first bin that starts in bucket b's range
+        bt[f] = (unsigned short)bf;
+    }
+    __syncthreads();
+    const int nb = nz ? (int)((nz - 1) / RK_T) + 1 : 0;
+    bool over = false;
+    for (int b = tid; b <= nbmax; b += RK_BT) {
+        meta_bstart(meta)[b] = bs[b];
+        meta_binfirst(meta, nbmax)[b] = bf0[b];
+        if (b < nbmax) meta_cursor(meta, nbmax)[b] = 0;
+        if (b < nb && bs[b + 1] - bs[b] > (unsigned)RK_CAP) over = true;
+    }
+    if (tid == 0) {
+        meta[0] = nz;
+        meta[1] = (unsigned)nb;
+        meta[2] = kmax[e] >> (20 - lgBPO);
+        meta[3] = kmax[e];
+    }
+    if (over) atomicOr(flag, 1u);
+}
+
+// Non-zero magnitudes (as bit patterns) and home indices into their buckets' ranges of mag / idx (per example n
+// entries, bucket b at [bstart[b], bstart[b+1])).  A step takes RK_TILE coefficients: they are counted per bucket,
+// gathered bucket by bucket in LDS and copied out from there, so that a wave's stores fall into a few runs of
+// consecutive addresses instead of one address per lane.  grid (G, B), RK_PT threads; dynamic LDS: btab, NF * 2 bytes.
+template <bool SINGLE>   // one workgroup per example: the cursors stay in LDS
+__global__ __launch_bounds__(RK_PT) void kr_part(const double* __restrict__ Y, size_t n, const unsigned short* __restrict__ btab,
+                                                 unsigned* meta_all, int NF, int lgBPO, unsigned long long* mag, unsigned* idx,
+                                                 const unsigned* flag) {
+    static_assert(RK_TILE == 4 * RK_PT && RK_NBMAX == 2 * RK_PT, "four coefficients and two buckets per thread");
+    extern __shared__ unsigned short rk_bt[];
+    __shared__ unsigned cnt[RK_NBMAX], gb[RK_NBMAX], bst[RK_NBMAX];
+    __shared__ unsigned short lst[RK_NBMAX];     // 78 KB with the rest: two workgroups per CU
+    __shared__ unsigned long long bitsL[RK_TILE];
+    __shared__ unsigned idxL[RK_TILE], dstL[RK_TILE];
+    __shared__ unsigned wsum[RK_PT / 64 + 1];
+    if (*flag) return;     // some bucket overflows: the caller will rank another way
+    const int e = blockIdx.y, tid = threadIdx.x;
+    const int nbmax = nbmax_for(n);
+    unsigned* meta = meta_all + (size_t)e * meta_words(n);
+    const unsigned Lmax = meta[2];
+    unsigned* cursor = meta_cursor(meta, nbmax);
+    for (int f = tid; f < NF; f += RK_PT) rk_bt[f] = btab[(size_t)e * NF + f];
+    for (int b = tid; b < RK_NBMAX; b += RK_PT) { cnt[b] = 0; bst[b] = (b < nbmax) ? meta_bstart(meta)[b] : 0u; }
+    lds_barrier();
+    const size_t per = n / gridDim.x, first = (size_t)blockIdx.x * per, last = first + per;
+    const double* src = Y + (size_t)e * n;
+    unsigned long long* mo = mag + (size_t)e * n;
+    unsigned* io = idx + (size_t)e * n;
+    double2 nx[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const size_t i = first + 2 * (size_t)(k * RK_PT + tid);
+        nx[k] = (i < last) ? *reinterpret_cast<const double2*>(src + i) : make_double2(0.0, 0.0);
+    }
+    for (size_t i0 = first; i0 < last; i0 += RK_TILE) {
+        unsigned long long bits[4];
+        unsigned short bk[4];
+        unsigned o[4];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const double2 v = nx[k];
+            bits[2 * k] = (unsigned long long)__double_as_longlong(v.x) & 0x7FFFFFFFFFFFFFFFull;
+            bits[2 * k + 1] = (unsigned long long)__double_as_longlong(v.y) & 0x7FFFFFFFFFFFFFFFull;
+            // (v != 0) rather than (bits != 0): the same test as everywhere else, true for NaN
+            if (!(v.x != 0.0)) bits[2 * k] = 0;
+            if (!(v.y != 0.0)) bits[2 * k + 1] = 0;
+            const size_t i = i0 + RK_TILE + 2 * (size_t)(k * RK_PT + tid);      // the next step's coefficients, on their way early
+            nx[k] = (i < last) ? *reinterpret_cast<const double2*>(src + i) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            bk[k] = 0;
+            o[k] = 0;
+            if (bits[k]) {
+                bk[k] = rk_bt[fine_bin((unsigned)(bits[k] >> 32), Lmax, lgBPO, NF)];
+                o[k] = atomicAdd(&cnt[bk[k]], 1u);
+            }
+        }
+        lds_barrier();
+        unsigned total;
+        {   // where each bucket's coefficients of this step start: in the LDS copy (lst) and in the staging arrays (gb)
+            const unsigned c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
+            const unsigned run = block_exclusive_scan<RK_PT>(c0 + c1, wsum, &total);
+            lst[2 * tid] = (unsigned short)run;
+            lst[2 * tid + 1] = (unsigned short)(run + c0);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int b = 2 * tid + h;
+                const unsigned c = h ? c1 : c0;
+                if (c) {
+                    if (SINGLE) { gb[b] = bst[b]; bst[b] += c; }
+                    else gb[b] = bst[b] + atomicAdd(&cursor[b], c);
+                    cnt[b] = 0;
+                }
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (bits[k]) {
+                const size_t i = i0 + 2 * (size_t)((k >> 1) * RK_PT + tid) + (k & 1);
+                const unsigned lp = lst[bk[k]] + o[k];
+                bitsL[lp] = bits[k];
+                idxL[lp] = (unsigned)i;
+                dstL[lp] = gb[bk[k]] + o[k];
+            }
+        }
+        lds_barrier();
+        for (unsigned p = tid; p < total; p += RK_PT) {
+            const unsigned d = dstL[p];
+            mo[d] = bitsL[p];
+            io[d] = idxL[p];
+        }
+    }
+}
+
+// LDS of kr_bucket.  64.6 KB: two workgroups of 512 threads per CU (the kernel wants about 100 registers per
+// thread), so that one's loads and barriers hide behind the other's LDS work.
+struct BucketLds {
+    unsigned long long keyB[RK_CAP];
+    unsigned idxB[RK_CAP], st[RK_NSB + 4];
+    unsigned wsum[RK_KT / 64 + 1];
+    unsigned long long wlo[RK_KT / 64], whi[RK_KT / 64];
+    double red[2 * (RK_KT / 64)];
+};
+
+// The sorting part of kr_bucket.  Sub-bin = the leading 12 bits of (magnitude - lo).  PACKED: what is left of the
+// magnitude below those bits, with the home index behind it, is ONE 64-bit key (both fit, except for a bucket that
+// spans dozens of octaves: the lowest one), the order inside a sub-bin is one comparison per pair, and from the keys
+// on a magnitude is carried as its key only (bits = lo + (sub-bin << sh) + key's upper part).  Otherwise magnitudes
+// and indices are kept side by side.  Returns through `bits` the magnitudes' bit patterns and through `o` their
+// ranks inside the bucket; writes the ranks home.
+template <bool PACKED>
+__device__ __forceinline__ void bucket_sort(BucketLds& L, unsigned long long (&bits)[RK_KE], unsigned (&id)[RK_KE], unsigned (&o)[RK_KE],
+                                            unsigned count, unsigned long long lo, int sh, int lgn, unsigned* rk, unsigned rank0) {
+    const int tid = threadIdx.x;
+    const unsigned long long remmask = sh ? ((1ull << sh) - 1ull) : 0ull;
+    const unsigned idmask = (1u << lgn) - 1u;          // lgn <= RK_LGN_MAX
+    unsigned sb[RK_KE];
+#pragma unroll
+    for (int k = 0; k < RK_KE; k++) {
+        const unsigned long long rel = bits[k] - lo;
+        sb[k] = (unsigned)(rel >> sh);
+        if (PACKED) bits[k] = ((rel & remmask) << lgn) | id[k];
+        o[k] = 0;
+        if (tid + k * RK_KT < count) o[k] = atomicAdd(&L.st[sb[k]], 1u);
+    }
+    lds_barrier();
+    {   // counts -> exclusive prefix sums, in place: RK_KE consecutive sub-bins per thread
+        unsigned c4[RK_KE], s = 0;
+#pragma unroll
+        for (int k = 0; k < RK_KE; k++) { c4[k] = L.st[RK_KE * tid + k]; s += c4[k]; }
+        unsigned run = block_exclusive_scan<RK_KT>(s, L.wsum, nullptr);
+#pragma unroll
+        for (int k = 0; k < RK_KE; k++) { L.st[RK_KE * tid + k] = run; run += c4[k]; }
+        if (tid == RK_KT - 1) L.st[RK_NSB] = run;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < RK_KE; k++) {
+        if (tid + k * RK_KT < count) {
+            const unsigned pos = L.st[sb[k]] + o[k];
+            L.keyB[pos] = bits[k];
+            if (!PACKED) L.idxB[pos] = id[k];
+        }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < RK_KE; k++) {
+        if (tid + k * RK_KT < count) {
+            const unsigned g0 = L.st[sb[k]], g1 = L.st[sb[k] + 1];
+            unsigned r = g0;
+            if (g1 - g0 > 1) {
+                if (PACKED) {
+                    for (unsigned q = g0; q < g1; q++) r += (L.keyB[q] < bits[k]) ? 1u : 0u;
+                } else {
+                    for (unsigned q = g0; q < g1; q++) {
+                        const unsigned long long kq = L.keyB[q];
+                        r += (kq < bits[k] || (kq == bits[k] && L.idxB[q] < id[k])) ? 1u : 0u;
+                    }
+                }
+            }
+            const unsigned home = PACKED ? ((unsigned)bits[k] & idmask) : id[k];
+            rk[home] = rank0 + r;
+            o[k] = r;
+            if (PACKED) bits[k] = lo + ((unsigned long long)sb[k] << sh) + (bits[k] >> lgn);
+        }
+    }
+}
+
+// One bucket: exact ranks home, the bucket's share of f = sum (2 rank - n - 1) |c| and of sum |c|.
+// 1D grid of nbmax * (examples rounded up to 8) workgroups: consecutive workgroups go to consecutive XCDs, so
+// workgroup L works on example (L / 8 / nbmax) * 8 + L % 8 -- all buckets of an example share one XCD, whose L2
+// then collects the example's scattered ranks into whole lines.
+__global__ __launch_bounds__(RK_KT, 4) void kr_bucket(const unsigned long long* __restrict__ mag, const unsigned* __restrict__ idx, size_t n,
+                                                      unsigned* meta_all, unsigned* rank, int B, const unsigned* flag, int NF, int lgBPO) {
+    __shared__ BucketLds L;
+    static_assert(RK_NSB == RK_KE * RK_KT && RK_CAP == RK_KE * RK_KT, "RK_KE sub-bins and RK_KE magnitudes per thread");
+    const int nbmax = nbmax_for(n);
+    const int slot = blockIdx.x >> 3;
+    const int e = (slot / nbmax) * 8 + (blockIdx.x & 7), b = slot % nbmax;
+    if (e >= B || *flag) return;
+    unsigned* meta = meta_all + (size_t)e * meta_words(n);
+    const unsigned nz = meta[0];
+    if (b >= (int)meta[1]) return;
+    const unsigned s0 = meta_bstart(meta)[b], count = meta_bstart(meta)[b + 1] - s0;
+    if (count == 0 || count > (unsigned)RK_CAP) return;      // an overfull bucket has raised the flag already
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned zeros = (unsigned)n - nz;
+    const unsigned long long* mi = mag + (size_t)e * n + s0;
+    const unsigned* ii = idx + (size_t)e * n + s0;
+    unsigned long long bits[RK_KE];
+    unsigned id[RK_KE], o[RK_KE];
+#pragma unroll
+    for (int k = 0; k < RK_KE; k++) {
+        const unsigned j = tid + k * RK_KT;
+        bits[k] = 0;
+        id[k] = 0;
+        if (j < count) {
+            bits[k] = mi[j];
+            id[k] = ii[j];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RK_KE; k++) L.st[RK_KE * tid + k] = 0;   // counts first, their prefix sums later
+    // the range of the bucket's magnitudes, from the bins it is made of
+    unsigned long long lo, hi;
+    {
+        const unsigned f0 = meta_binfirst(meta, nbmax)[b], fnext = meta_binfirst(meta, nbmax)[b + 1];
+        bin_range(f0, (fnext > f0 ? fnext : (unsigned)NF) - 1u, meta[2], meta[3], lgBPO, NF, &lo, &hi);
+        if (f0 == 0) {
+            // the lowest bin reaches down to zero: take the bucket's own smallest and largest magnitude instead, or a few
+            // stragglers far below the rest would leave everything else in a handful of sub-bins
+            lo = ~0ull;
+            hi = 0;
+#pragma unroll
+            for (int k = 0; k < RK_KE; k++) {
+                if (tid + k * RK_KT < count) {
+                    lo = bits[k] < lo ? bits[k] : lo;
+                    hi = bits[k] > hi ? bits[k] : hi;
+                }
+            }
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) {
+                const unsigned long long l2 = (unsigned long long)__shfl_xor((long long)lo, s, 64), h2 = (unsigned long long)__shfl_xor((long long)hi, s, 64);
+                lo = l2 < lo ? l2 : lo;
+                hi = h2 > hi ? h2 : hi;
+            }
+            if (lane == 0) { L.wlo[wave] = lo; L.whi[wave] = hi; }
+            lds_barrier();
+#pragma unroll
+            for (int w = 0; w < RK_KT / 64; w++) {
+                lo = L.wlo[w] < lo ? L.wlo[w] : lo;
+                hi = L.whi[w] > hi ? L.whi[w] : hi;
+            }
+        }
+    }
+    lds_barrier();
+    int lgn = 0;
+    while (((size_t)1 << lgn) < n) lgn++;
+    const unsigned long long span = hi - lo;
+    const int sh = (span >> 12) ? (64 - __builtin_clzll(span) - 12) : 0;   // (span >> sh) < RK_NSB = 4096
+    unsigned* rk = rank + (size_t)e * n;
+    if (sh + lgn <= 64) bucket_sort<true>(L, bits, id, o, count, lo, sh, lgn, rk, zeros + s0 + 1u);
+    else bucket_sort<false>(L, bits, id, o, count, lo, sh, lgn, rk, zeros + s0 + 1u);
+    lds_barrier();       // every comparison has read its keys: the array now takes the magnitudes in sorted order
+    unsigned long long* magS = L.keyB;
+#pragma unroll
+    for (int k = 0; k < RK_KE; k++) {
+        if (tid + k * RK_KT < count) magS[o[k]] = bits[k];
+    }
+    lds_barrier();
+    double f = 0, a = 0;
+    for (unsigned r = tid; r < count; r += RK_KT) {
+        const double av = __longlong_as_double((long long)magS[r]);
+        f = __builtin_fma(2.0 * (double)(zeros + s0 + r + 1u) - (double)n - 1.0, av, f);
+        a += av;
+    }
+    f = wave_sum(f);
+    a = wave_sum(a);
+    if (lane == 0) { L.red[wave] = f; L.red[RK_KT / 64 + wave] = a; }
+    lds_barrier();
+    if (tid < 2) {
+        double t = 0;
+        for (int w = 0; w < RK_KT / 64; w++) t += L.red[tid * (RK_KT / 64) + w];
+        meta_bpart(meta, nbmax)[2 * b + tid] = t;
+    }
+}
+
+// fg[2e] = f, fg[2e+1] = g = n sum |c|, S_e[e] = 1 - f / g: the buckets' shares in bucket order.
+__global__ void kr_finish(unsigned* meta_all, size_t n, int B, double* fg, double* S_e) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B) return;
+    const int nbmax = nbmax_for(n);
+    unsigned* meta = meta_all + (size_t)e * meta_words(n);
+    const int nb = (int)meta[1];
+    const double* bp = meta_bpart(meta, nbmax);
+    double f = 0, a = 0;
+    for (int b = 0; b < nb; b++) {
+        if (meta_bstart(meta)[b + 1] != meta_bstart(meta)[b]) { f += bp[2 * b]; a += bp[2 * b + 1]; }
+    }
+    const double g = (double)n * a;
+    fg[2 * e] = f;
+    fg[2 * e + 1] = g;
+    if (S_e) S_e[e] = 1.0 - f / g;
+}
+
+}  // namespace rk
+}  // namespace wn
