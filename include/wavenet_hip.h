@@ -276,6 +276,13 @@ int wn_comm_unique_id(void* id128_host);
 int wn_comm_init(wn_context* ctx, const void* id128_host, int nranks, int rank);
 int wn_comm_destroy(wn_context* ctx);
 int wn_allreduce_sums(wn_context* ctx);
+/*
+ * The same for ONE process that drives several GPUs from one host thread (the host layer's data-parallel
+ * Coach): communicators for all n contexts at once (every context on a GPU of its own), and the all-reduce
+ * of all of them as one group, each on its context's stream.
+ */
+int wn_comm_init_all(wn_context** ctxs, int n);
+int wn_allreduce_sums_all(wn_context** ctxs, int n);
 
 #ifdef __cplusplus
 }

@@ -112,6 +112,7 @@ int main(int argc, char** argv) {
         w.setBatchSize(batch);
         if (inertia > 0) w.setInertia(inertia);
         if (timeScale > 0) w.setInertiaTimeScale(timeScale);
+        if (const char* rep = std::getenv("WAVENET_TEST_REPLICAS")) w.setDevices(std::vector<int>((size_t)std::atoi(rep), 0), false);
         if (!w.setFilter(Col(N, in.data()))) return 3;
         if (batched) {
             // an odd split exercises the pending-queue path between device rounds
@@ -210,6 +211,10 @@ int main(int argc, char** argv) {
         coach.setUseSimulatedAnnealing((flags >> 2) & 1u);
         if (target > 0) coach.setTargetPrecision(target);
         if (const char* inits = std::getenv("WAVENET_TEST_NUM_INITS")) coach.setNumInits(std::atoi(inits));
+        if (const char* rep = std::getenv("WAVENET_TEST_REPLICAS")) {
+            // that many shares of every batch, all on GPU 0, their sums added on the host in replica order
+            coach.setDevices(std::vector<int>((size_t)std::atoi(rep), 0), false);
+        }
         if (const char* al = std::getenv("WAVENET_TEST_ALPHA")) w.setAlpha(std::atof(al));
         if (std::getenv("WAVENET_TEST_HOST_GENERATE")) coach.setGenerateOnDevice(false);
         if (const char* dir = std::getenv("WAVENET_TEST_SNAPSHOT_DIR")) {   // relative directory for the snapshots

@@ -81,3 +81,40 @@ def test_trainer_through_a_nccl_group_of_one_rank():
         ctx.close()
         if created:
             dist.destroy_process_group()
+
+
+def test_single_process_communicators_of_one_gpu():
+    """wn_comm_init_all / wn_allreduce_sums_all (one host thread driving every GPU, as the host layer's data-parallel
+    Coach does) with the one GPU there is: the grouped all-reduce returns the sums unchanged, wn_train_step on a
+    context that holds a communicator lands on the plain update's filter, and two contexts on one GPU are refused."""
+    import ctypes as C
+    import torch
+    from wavenet_amd import Context
+    from wavenet_amd.capi import WN_ERR_ARG, WN_OK
+    X = _inputs()
+    B, R, Cc = X.shape
+    a = F.perturbed(F.daubechies(4), 1e-2, 1)
+    dX = to_dev(X)
+    ctx = Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    other = Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    ref = Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        arr2 = (C.c_void_p * 2)(ctx._h, other._h)
+        assert ctx.lib.wn_comm_init_all(arr2, 2) == WN_ERR_ARG
+        arr1 = (C.c_void_p * 1)(ctx._h)
+        assert ctx.lib.wn_comm_init_all(arr1, 1) == WN_OK
+        for c in (ctx, ref):
+            c.set_filter(a)
+        ctx.train_batch(dX, B, R, Cc)
+        before = ctx.sums().copy()
+        assert ctx.lib.wn_allreduce_sums_all(arr1, 1) == WN_OK
+        assert np.array_equal(before, ctx.sums())
+        for _ in range(3):
+            ctx.train_step(dX, B, R, Cc, B, B * 10.0, 1e-3, 0.0, True)
+            ref.train_batch(dX, B, R, Cc)
+            ref.apply_update(B, B * 10.0, 1e-3, 0.0, True)
+        assert np.array_equal(ctx.filter(), ref.filter())
+    finally:
+        ctx.close()
+        other.close()
+        ref.close()

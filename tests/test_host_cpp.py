@@ -144,6 +144,53 @@ def test_coach_run_matches_oracle(oracle, flags, events, epochs, batch, target, 
     assert lam == pytest.approx(w.lam(), rel=1e-14) and alpha == w.alpha() and bs == w.batch_size()
 
 
+@pytest.mark.parametrize("flags,events,batch", [(0, 96, 8), (3, 480, 4), (4, 120, 6), (2, 300, 3)])
+def test_data_parallel_coach_is_shard_invariant(oracle, flags, events, batch):
+    """Coach::run with every batch split over 1, 2, 4 and 8 replicas (all on GPU 0, sums added on the host in
+    replica order -- the stand-in for the RCCL all-reduce): the filter log must not depend on the number of
+    shares beyond the rounding of a re-ordered sum, and must equal the oracle's serial run.  Batches of 3, 4
+    and 6 leave some replicas without examples or with unequal shares; the adaptive batch size changes the
+    shares in mid-run."""
+    from wavenet_amd import generators as G
+    R, C, N, seed = 8, 8, 4, 42
+    a = F.perturbed(F.DB4, 5e-2, 5)
+    logs = {}
+    for replicas in (1, 2, 4, 8):
+        out, _ = run_driver(["coach", R, C, N, events, 1, batch, flags, seed, -1], [a], env={"WAVENET_TEST_REPLICAS": str(replicas)})
+        logs[replicas] = (out["filterLog"].reshape(-1, N), out["costLog"], out["misc"])
+    w = oracle.Wavenet(lam=10.0, alpha=1e-3)
+    w.set_batch_size(batch)
+    w.coach_run(a, G.uniform(events, R, C, seed=seed), events, num_epochs=1, adaptive_lr=bool(flags & 1),
+                adaptive_batch=bool(flags & 2), annealing=bool(flags & 4), target_precision=-1)
+    for replicas, (fl, cl, misc) in logs.items():
+        assert fl.shape == logs[1][0].shape, replicas
+        assert np.allclose(fl, logs[1][0], rtol=1e-12, atol=0), replicas
+        assert np.allclose(cl, logs[1][1], rtol=1e-12, atol=1e-15), replicas
+        assert np.array_equal(misc, logs[1][2])
+        assert np.allclose(fl, w.filter_log(), rtol=1e-9, atol=0)
+        assert np.allclose(cl, w.cost_log(), rtol=1e-9, atol=1e-15)
+
+
+@pytest.mark.parametrize("replicas", [2, 3])
+def test_data_parallel_train_batch_with_a_pending_queue(oracle, replicas):
+    """trainBatch in two calls that do not end on batch boundaries: whole batches go over the replicas, the
+    rest through the queue on the first device, and the replicas follow every update."""
+    R, C, N, E, batch = 16, 16, 4, 50, 8
+    rng = np.random.default_rng(E + N)
+    a = F.perturbed(F.daubechies(N), 1e-2, 2)
+    X = rng.random((E, R, C))
+    flat = np.concatenate([colmajor(x) for x in X])
+    out, _ = run_driver(["train", R, C, N, E, batch, 0.5, 1], [a, flat], env={"WAVENET_TEST_REPLICAS": str(replicas)})
+    w = oracle.Wavenet(lam=10.0, alpha=1e-3)
+    w.set_batch_size(batch)
+    w.set_inertia(0.5)
+    w.set_filter(a)
+    for x in X:
+        w.train(x)
+    assert np.allclose(out["filterLog"].reshape(-1, N), w.filter_log(), rtol=1e-9, atol=0)
+    assert np.allclose(out["costLog"], w.cost_log(), rtol=1e-9, atol=1e-15)
+
+
 def test_coach_stops_on_a_diverging_solution():
     """A learning rate far too large drives the filter to infinity within a few updates.  The reference's
     train() then returns false and Coach::run ends the initialisation (src/Wavenet.cxx:234-241,

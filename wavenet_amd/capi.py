@@ -65,6 +65,8 @@ SIGNATURES = {
     "wn_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "wn_comm_destroy": (C.c_int, [_vp]),
     "wn_allreduce_sums": (C.c_int, [_vp]),
+    "wn_comm_init_all": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "wn_allreduce_sums_all": (C.c_int, [C.POINTER(_vp), C.c_int]),
 }
 
 

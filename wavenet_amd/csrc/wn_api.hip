@@ -895,6 +895,60 @@ int wn_comm_init(wn_context* ctx, const void* id128, int nranks, int rank) {
     return WN_OK;
 }
 
+// One process, one host thread, several GPUs: all communicators at once (ncclCommInitAll) and the all-reduce
+// of every context inside one group call, so that no call waits for a rank the same thread has yet to serve.
+typedef int (*fn_ncclCommInitAll)(void**, int, const int*);
+typedef int (*fn_ncclGroup)(void);
+
+int wn_comm_init_all(wn_context** ctxs, int n) {
+    if (!ctxs || n < 1 || n > 64) return WN_ERR_ARG;
+    for (int r = 0; r < n; r++) {
+        if (!ctxs[r]) return WN_ERR_ARG;
+        if (ctxs[r]->comm) return fail(ctxs[r], WN_ERR_STATE, "communicator already initialised");
+        for (int q = 0; q < r; q++) {
+            if (ctxs[q]->device == ctxs[r]->device)
+                return fail(ctxs[r], WN_ERR_ARG, "RCCL needs every context on a GPU of its own (device " + std::to_string(ctxs[r]->device) + " appears twice)");
+        }
+    }
+    void* lib = open_rccl();
+    if (!lib) return fail(ctxs[0], WN_ERR_COMM, std::string("dlopen librccl: ") + dlerror());
+    auto f = (fn_ncclCommInitAll)dlsym(lib, "ncclCommInitAll");
+    if (!f) return fail(ctxs[0], WN_ERR_COMM, "ncclCommInitAll not found");
+    std::vector<void*> comms((size_t)n, nullptr);
+    std::vector<int> devs((size_t)n);
+    for (int r = 0; r < n; r++) devs[(size_t)r] = ctxs[r]->device;
+    const int rc = f(comms.data(), n, devs.data());
+    if (rc != 0) return fail(ctxs[0], WN_ERR_COMM, "ncclCommInitAll failed: " + std::to_string(rc));
+    for (int r = 0; r < n; r++) {
+        ctxs[r]->nccl_lib = lib;
+        ctxs[r]->comm = comms[(size_t)r];
+        ctxs[r]->nranks = n;
+    }
+    return WN_OK;
+}
+
+int wn_allreduce_sums_all(wn_context** ctxs, int n) {
+    if (!ctxs || n < 1) return WN_ERR_ARG;
+    for (int r = 0; r < n; r++) {
+        if (!ctxs[r]) return WN_ERR_ARG;
+        if (!ctxs[r]->has_filter) return fail(ctxs[r], WN_ERR_STATE, "no filter set");
+        if (!ctxs[r]->comm || ctxs[r]->nranks != n) return fail(ctxs[r], WN_ERR_STATE, "no communicator over these contexts: call wn_comm_init_all first");
+    }
+    void* lib = ctxs[0]->nccl_lib;
+    auto ar = (fn_ncclAllReduce)dlsym(lib, "ncclAllReduce");
+    auto gs = (fn_ncclGroup)dlsym(lib, "ncclGroupStart");
+    auto ge = (fn_ncclGroup)dlsym(lib, "ncclGroupEnd");
+    if (!ar || !gs || !ge) return fail(ctxs[0], WN_ERR_COMM, "ncclAllReduce / ncclGroupStart / ncclGroupEnd not found");
+    int rc = gs();
+    for (int r = 0; r < n && rc == 0; r++) {
+        wn_context* c = ctxs[r];
+        rc = ar(c->sums, c->sums, (size_t)(c->N + 2), kNcclDouble, kNcclSum, c->comm, c->stream);
+    }
+    const int rc2 = ge();
+    if (rc != 0 || rc2 != 0) return fail(ctxs[0], WN_ERR_COMM, "grouped ncclAllReduce failed: " + std::to_string(rc ? rc : rc2));
+    return WN_OK;
+}
+
 int wn_comm_destroy(wn_context* ctx) {
     if (!ctx) return WN_ERR_ARG;
     if (ctx->comm && ctx->nccl_lib) {

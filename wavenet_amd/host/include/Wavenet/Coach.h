@@ -42,6 +42,8 @@ public:
     // examples are generated on the device when the generator can do that (default); off: always next()
     void setGenerateOnDevice(bool flag = true) { m_generateOnDevice = flag; }
     bool generateOnDevice() const { return m_generateOnDevice; }
+    // Data-parallel batch loop: the GPUs the wavenet's batches are sharded over (Wavenet::setDevices); set before run().
+    void setDevices(const std::vector<int>& devices, bool useRccl = true) { m_devices = devices; m_useRccl = useRccl; }
     // write outdir()/snapshots/<name>.<init, 6 digits>.snap after every initialisation (default: off)
     void setSaveSnapshots(bool flag = true) { m_saveSnapshots = flag; }
     bool saveSnapshots() const { return m_saveSnapshots; }
@@ -83,6 +85,8 @@ private:
     std::uint64_t m_seed = 1;
     bool m_generateOnDevice = true;
     bool m_saveSnapshots = false;
+    std::vector<int> m_devices;
+    bool m_useRccl = true;
 };
 
 }  // namespace wavenet

@@ -64,6 +64,16 @@ public:
     bool doWavelet(const bool& wavelet) { m_wavelet = wavelet; return true; }
     // GPU to run on (default 0); takes effect before the first device call.
     void setDevice(int device) { m_device = device; }
+    // Data-parallel training over several GPUs of the node: every whole batch of trainBatch / trainBatchFrom
+    // is split into contiguous shares, one per entry of `devices` (share r holds examples [r B / G, (r + 1) B / G)
+    // in the sense of the sizes differing by at most one), each GPU runs forward, sparsity gradient and
+    // backpropagation on its share, the N + 2 sums are added over the GPUs and every replica applies the same
+    // update (src/Wavenet.cxx:717-765 is the one place where examples of a batch meet).  The sums travel by RCCL
+    // (wn_comm_init_all / wn_allreduce_sums_all); with useRccl false they are added on the host in device order,
+    // which also allows one GPU to appear several times (several shares on one card, for tests).  Takes effect
+    // before the first device call; the first entry also becomes the device of everything else.
+    void setDevices(const std::vector<int>& devices, bool useRccl = true);
+    unsigned numReplicas() const { return m_devices.empty() ? 1u : (unsigned)m_devices.size(); }
 
     void print() const;
 
@@ -129,6 +139,12 @@ private:
     friend const Snapshot& operator>>(const Snapshot& snap, Wavenet& wavenet);
 
     DeviceSession& device_();
+    // Runs f(session) on the session of every replica, the first one included; false as soon as one fails.
+    template <class F> bool onReplicas_(F f);
+    // Whole batches over all replicas: place(r, dst, first, count) puts examples [first, first + count) of the call
+    // on replica r's device at dst; it is called in the order of the examples.
+    template <class Place> bool trainSharded_(Place place, unsigned nb, unsigned done, unsigned nRows, unsigned nCols, const double* lambdas);
+    bool exchangeSums_();
     bool checkShape_(unsigned nRows, unsigned nCols) const;
     // forward + sparsity gradient + backpropagation of `count` examples already on the device,
     // per-example results into the batch queue and the cost log (the slow, exact path of train()).
@@ -149,6 +165,9 @@ private:
     bool m_wavelet = true;
     int m_device = 0;
     DeviceSession* m_session = nullptr;
+    std::vector<int> m_devices;               // data-parallel: one entry per replica (empty: single device)
+    std::vector<DeviceSession*> m_replicas;   // sessions of the replicas 1 .. G-1 (replica 0 is m_session)
+    bool m_useRccl = true;
 };
 
 template <class T>

@@ -55,6 +55,7 @@ bool Coach::run() {
         return false;
     }
 
+    if (!m_devices.empty()) m_wavenet->setDevices(m_devices, m_useRccl);
     const unsigned useLastN = 10;                       // :120
     const double lambdaBare = m_wavenet->lambda();      // :123
     const double alphaBare = m_wavenet->alpha();        // the reference restores these from its base snapshot (:138)

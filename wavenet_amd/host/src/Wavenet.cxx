@@ -69,16 +69,56 @@ Wavenet::Wavenet(const double& lambda, const double& alpha) : m_lambda(lambda), 
 Wavenet::Wavenet(const Wavenet& other)
     : m_lambda(other.m_lambda), m_alpha(other.m_alpha), m_inertia(other.m_inertia),
       m_inertiaTimeScale(other.m_inertiaTimeScale), m_filter(other.m_filter), m_device(other.m_device) {}
-Wavenet::~Wavenet() { delete m_session; }
+Wavenet::~Wavenet() {
+    for (DeviceSession* r : m_replicas) delete r;
+    delete m_session;
+}
+
+void Wavenet::setDevices(const std::vector<int>& devices, bool useRccl) {
+    if (m_session) {
+        WARNING("setDevices() has no effect after the first device call.");
+        return;
+    }
+    m_devices = devices;
+    m_useRccl = useRccl;
+    if (!devices.empty()) m_device = devices[0];
+}
+
+template <class F>
+bool Wavenet::onReplicas_(F f) {
+    if (m_session && !f(*m_session)) return false;
+    for (DeviceSession* r : m_replicas) {
+        if (!f(*r)) return false;
+    }
+    return true;
+}
 
 DeviceSession& Wavenet::device_() {
     if (!m_session) {
         m_session = new DeviceSession(m_device);
-        if (m_session->ctx && !m_filter.is_empty()) {
-            m_session->ok(wn_set_filter(m_session->ctx, m_filter.memptr(), (int)m_filter.n_elem));
-            if (m_momentum.n_elem == m_filter.n_elem)
-                m_session->ok(wn_set_momentum(m_session->ctx, m_momentum.memptr(), (int)m_momentum.n_elem));
+        for (std::size_t r = 1; r < m_devices.size() && m_session->ctx; r++) {
+            m_replicas.push_back(new DeviceSession(m_devices[r]));
+            if (!m_replicas.back()->ctx) {   // without all of its replicas the object runs on the first device alone
+                for (DeviceSession* q : m_replicas) delete q;
+                m_replicas.clear();
+                m_devices.clear();
+                break;
+            }
         }
+        if (!m_replicas.empty() && m_useRccl) {
+            std::vector<wn_context*> ctxs(1, m_session->ctx);
+            for (DeviceSession* q : m_replicas) ctxs.push_back(q->ctx);
+            if (!m_session->ok(wn_comm_init_all(ctxs.data(), (int)ctxs.size()))) {
+                WARNING("No RCCL communicator over the replicas: their sums are added on the host instead.");
+                m_useRccl = false;
+            }
+        }
+        onReplicas_([&](DeviceSession& d) {
+            if (!d.ctx || m_filter.is_empty()) return true;
+            d.ok(wn_set_filter(d.ctx, m_filter.memptr(), (int)m_filter.n_elem));
+            if (m_momentum.n_elem == m_filter.n_elem) d.ok(wn_set_momentum(d.ctx, m_momentum.memptr(), (int)m_momentum.n_elem));
+            return true;
+        });
     }
     return *m_session;
 }
@@ -109,19 +149,14 @@ bool Wavenet::setFilter(const Col& filter) {
     m_filter = filter;
     m_filterLog.push_back(m_filter);
     if (m_momentum.n_elem != m_filter.n_elem) m_momentum.zeros(m_filter.n_elem);
-    if (m_session && m_session->ctx) {
-        // stands for clearCachedOperators_(): the device taps are what the operators were built from
-        if (!m_session->ok(wn_set_filter(m_session->ctx, m_filter.memptr(), (int)m_filter.n_elem))) return false;
-    }
-    return true;
+    // stands for clearCachedOperators_(): the device taps are what the operators were built from
+    return onReplicas_([&](DeviceSession& d) { return !d.ctx || d.ok(wn_set_filter(d.ctx, m_filter.memptr(), (int)m_filter.n_elem)); });
 }
 
 bool Wavenet::setMomentum(const Col& momentum) {
     assert(momentum.size() == m_filter.size());
     m_momentum = momentum;
-    if (m_session && m_session->ctx)
-        return m_session->ok(wn_set_momentum(m_session->ctx, m_momentum.memptr(), (int)m_momentum.n_elem));
-    return true;
+    return onReplicas_([&](DeviceSession& d) { return !d.ctx || d.ok(wn_set_momentum(d.ctx, m_momentum.memptr(), (int)m_momentum.n_elem)); });
 }
 
 /// Get method(s).
@@ -179,11 +214,12 @@ void Wavenet::load(Snapshot snap) {
     }
     snap >> *this;
     // the loaded taps replace whatever the device-side operators were built from
-    if (m_session && m_session->ctx && !m_filter.is_empty()) {
-        m_session->ok(wn_set_filter(m_session->ctx, m_filter.memptr(), (int)m_filter.n_elem));
-        if (m_momentum.n_elem == m_filter.n_elem)
-            m_session->ok(wn_set_momentum(m_session->ctx, m_momentum.memptr(), (int)m_momentum.n_elem));
-    }
+    onReplicas_([&](DeviceSession& d) {
+        if (!d.ctx || m_filter.is_empty()) return true;
+        d.ok(wn_set_filter(d.ctx, m_filter.memptr(), (int)m_filter.n_elem));
+        if (m_momentum.n_elem == m_filter.n_elem) d.ok(wn_set_momentum(d.ctx, m_momentum.memptr(), (int)m_momentum.n_elem));
+        return true;
+    });
 }
 
 bool Wavenet::checkShape_(unsigned nRows, unsigned nCols) const {
@@ -238,9 +274,23 @@ bool Wavenet::trainBatch(const double* X, unsigned B, unsigned nRows, unsigned n
     DeviceSession& dev = device_();
     if (!dev.ctx) return false;
     const std::size_t n = (std::size_t)nRows * nCols;
-    double* dX = dev.buf(DeviceSession::X, (std::size_t)B * n);
-    if (!dev.up(dX, X, (std::size_t)B * n)) return false;
-    return trainOnDevice_(dX, B, nRows, nCols, lambdas);
+    unsigned done = 0;
+    if (!m_replicas.empty() && m_batchQueue.empty() && B >= m_batchSize) {
+        // whole batches go over all replicas, straight from the caller's memory
+        auto place = [&](unsigned r, double* dst, unsigned first, unsigned count) {
+            DeviceSession& d = r ? *m_replicas[r - 1] : dev;
+            return d.up(dst, X + (std::size_t)first * n, (std::size_t)count * n);
+        };
+        while (B - done >= m_batchSize) {
+            const unsigned nb = std::min((B - done) / m_batchSize, 8192u);   // the device keeps the last 16384 log entries
+            if (!trainSharded_(place, nb, done, nRows, nCols, lambdas)) return false;
+            done += nb * m_batchSize;
+        }
+        if (done == B) return true;
+    }
+    double* dX = dev.buf(DeviceSession::X, (std::size_t)(B - done) * n);
+    if (!dev.up(dX, X + (std::size_t)done * n, (std::size_t)(B - done) * n)) return false;
+    return trainOnDevice_(dX, B - done, nRows, nCols, lambdas ? lambdas + done : nullptr);
 }
 
 bool Wavenet::trainBatchFrom(GeneratorBase& generator, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas) {
@@ -248,9 +298,116 @@ bool Wavenet::trainBatchFrom(GeneratorBase& generator, unsigned B, unsigned nRow
     if (B == 0) return true;
     DeviceSession& dev = device_();
     if (!dev.ctx) return false;
-    double* dX = dev.buf(DeviceSession::X, (std::size_t)B * nRows * nCols);
-    if (!dX || !generator.nextOnDevice(dev.ctx, dX, B)) return false;
-    return trainOnDevice_(dX, B, nRows, nCols, lambdas);
+    unsigned done = 0;
+    if (!m_replicas.empty() && m_batchQueue.empty() && B >= m_batchSize) {
+        // every replica's share is generated where it is trained; the shares are taken in the order of the examples,
+        // so the generator's sequence is the one a single device would see
+        auto place = [&](unsigned r, double* dst, unsigned, unsigned count) {
+            DeviceSession& d = r ? *m_replicas[r - 1] : dev;
+            return generator.nextOnDevice(d.ctx, dst, count);
+        };
+        while (B - done >= m_batchSize) {
+            const unsigned nb = std::min((B - done) / m_batchSize, 8192u);
+            if (!trainSharded_(place, nb, done, nRows, nCols, lambdas)) return false;
+            done += nb * m_batchSize;
+        }
+        if (done == B) return true;
+    }
+    double* dX = dev.buf(DeviceSession::X, (std::size_t)(B - done) * nRows * nCols);
+    if (!dX || !generator.nextOnDevice(dev.ctx, dX, B - done)) return false;
+    return trainOnDevice_(dX, B - done, nRows, nCols, lambdas ? lambdas + done : nullptr);
+}
+
+// Contiguous share [begin, end) of `total` examples for replica r of G; sizes differ by at most one.
+static void shareOf(unsigned total, unsigned r, unsigned G, unsigned* begin, unsigned* end) {
+    const unsigned base = total / G, extra = total % G;
+    *begin = r * base + std::min(r, extra);
+    *end = *begin + base + (r < extra ? 1u : 0u);
+}
+
+// The sums of all replicas added up and handed back to every one of them.
+bool Wavenet::exchangeSums_() {
+    DeviceSession& dev = *m_session;
+    const unsigned G = (unsigned)m_replicas.size() + 1;
+    if (m_useRccl) {
+        std::vector<wn_context*> ctxs(1, dev.ctx);
+        for (DeviceSession* q : m_replicas) ctxs.push_back(q->ctx);
+        return dev.ok(wn_allreduce_sums_all(ctxs.data(), (int)G));
+    }
+    // on the host, in replica order: the same result whatever the timing
+    const int count = (int)m_filter.n_elem + 2;
+    std::vector<double> total((std::size_t)count, 0.0), part((std::size_t)count);
+    for (unsigned r = 0; r < G; r++) {
+        DeviceSession& d = r ? *m_replicas[r - 1] : dev;
+        int c = count;
+        if (!d.ok(wn_get_sums(d.ctx, part.data(), &c))) return false;
+        for (int k = 0; k < count; k++) total[(std::size_t)k] += part[(std::size_t)k];
+    }
+    return onReplicas_([&](DeviceSession& d) {
+        double* sums = nullptr;
+        int c = 0;
+        return d.ok(wn_sums(d.ctx, &sums, &c)) && d.up(sums, total.data(), (std::size_t)count);
+    });
+}
+
+template <class Place>
+bool Wavenet::trainSharded_(Place place, unsigned nb, unsigned first, unsigned nRows, unsigned nCols, const double* lambdas) {
+    DeviceSession& dev = *m_session;
+    const unsigned G = (unsigned)m_replicas.size() + 1;
+    const std::size_t n = (std::size_t)nRows * nCols;
+    const int N = (int)m_filter.n_elem;
+    // every replica's shares of all nb batches, batch after batch in its X buffer
+    std::vector<double*> dX(G);
+    std::vector<unsigned> shareSize(G), shareBegin(G);
+    for (unsigned r = 0; r < G; r++) {
+        unsigned b0, b1;
+        shareOf(m_batchSize, r, G, &b0, &b1);
+        shareBegin[r] = b0;
+        shareSize[r] = b1 - b0;
+        DeviceSession& d = r ? *m_replicas[r - 1] : dev;
+        dX[r] = d.buf(DeviceSession::X, std::max<std::size_t>(1, (std::size_t)nb * shareSize[r] * n));
+        if (!dX[r]) return false;
+    }
+    for (unsigned b = 0; b < nb; b++) {
+        for (unsigned r = 0; r < G; r++) {
+            if (shareSize[r] && !place(r, dX[r] + (std::size_t)b * shareSize[r] * n, first + b * m_batchSize + shareBegin[r], shareSize[r]))
+                return false;
+        }
+    }
+    int firstLog = 0;
+    if (wn_num_updates(dev.ctx, &firstLog) == WN_ERR_NONFINITE) return diverged_();
+    for (unsigned b = 0; b < nb; b++) {
+        double lambdaSum = 0;
+        for (unsigned e = 0; e < m_batchSize; e++) lambdaSum += lambdas ? lambdas[first + b * m_batchSize + e] : m_lambda;
+        const unsigned steps = (unsigned)m_costLog.size() - 1 + b;
+        for (unsigned r = 0; r < G; r++) {
+            DeviceSession& d = r ? *m_replicas[r - 1] : dev;
+            if (!d.ok(wn_train_batch(d.ctx, dX[r] + (std::size_t)b * shareSize[r] * n, (int)shareSize[r], (int)nRows, (int)nCols, nullptr, nullptr)))
+                return false;
+        }
+        if (!exchangeSums_()) return false;
+        const double inertia = effectiveInertia_(steps);
+        if (!onReplicas_([&](DeviceSession& d) { return d.ok(wn_apply_update(d.ctx, (double)m_batchSize, lambdaSum, m_alpha, inertia, m_wavelet)); }))
+            return false;
+    }
+    // every replica holds the same state: the logs come from the first
+    int lastLog = 0;
+    const int state = wn_num_updates(dev.ctx, &lastLog);
+    if (state != WN_OK && state != WN_ERR_NONFINITE) return dev.ok(state);
+    const unsigned applied = (unsigned)(lastLog - firstLog);
+    std::vector<double> F((std::size_t)applied * N), C(applied);
+    if (applied && !dev.ok(wn_get_logs(dev.ctx, firstLog, (int)applied, F.data(), C.data()))) return false;
+    for (unsigned b = 0; b < applied; b++) {
+        m_filterLog.push_back(Col(N, F.data() + (std::size_t)b * N));
+        m_costLog.back() = C[b];
+        m_costLog.push_back(0);
+    }
+    if (applied) m_filter = m_filterLog.back();
+    int nn = N;
+    if (!dev.ok(wn_get_momentum(dev.ctx, m_momentum.memptr(), &nn))) return false;
+    if (lambdas && applied) m_lambda = lambdas[first + applied * m_batchSize - 1];
+    if (state == WN_ERR_NONFINITE) return diverged_();
+    return true;
 }
 
 // B examples already on the device: whole batches back to back, the rest through the batch queue.
@@ -273,8 +430,8 @@ bool Wavenet::trainOnDevice_(const double* dX, unsigned B, unsigned nRows, unsig
                 for (unsigned e = 0; e < m_batchSize; e++)
                     lambdaSum += lambdas ? lambdas[done + b * m_batchSize + e] : m_lambda;
                 const unsigned steps = (unsigned)m_costLog.size() - 1 + b;
-                if (!dev.ok(wn_train_batch(dev.ctx, Xb, (int)m_batchSize, (int)nRows, (int)nCols, nullptr, nullptr))) return false;
-                if (!dev.ok(wn_apply_update(dev.ctx, (double)m_batchSize, lambdaSum, m_alpha, effectiveInertia_(steps), m_wavelet)))
+                if (!dev.ok(wn_train_step(dev.ctx, Xb, (int)m_batchSize, (int)nRows, (int)nCols, (double)m_batchSize, lambdaSum, m_alpha,
+                                          effectiveInertia_(steps), m_wavelet)))
                     return false;
             }
             // bring the logs and the state back; a batch with non-finite sums was not applied, nor was any
@@ -295,6 +452,10 @@ bool Wavenet::trainOnDevice_(const double* dX, unsigned B, unsigned nRows, unsig
             if (!dev.ok(wn_get_momentum(dev.ctx, m_momentum.memptr(), &nn))) return false;
             if (lambdas && applied) m_lambda = lambdas[done + applied * m_batchSize - 1];
             if (state == WN_ERR_NONFINITE) return diverged_();                          // :234-241
+            // batches that ran on the first device alone (a pending queue came first): the replicas follow
+            for (DeviceSession* r : m_replicas) {
+                if (!r->ok(wn_set_filter(r->ctx, m_filter.memptr(), N)) || !r->ok(wn_set_momentum(r->ctx, m_momentum.memptr(), N))) return false;
+            }
             done += nb * m_batchSize;
         } else {
             // fill the pending batch (or a trailing partial one) example by example
@@ -318,10 +479,13 @@ void Wavenet::clear() {
     scaleMomentum_(0.);
     clearFilterLog();
     clearCostLog();
-    if (m_session && m_session->ctx) {
-        wn_set_momentum(m_session->ctx, m_momentum.memptr(), (int)m_momentum.n_elem);
-        wn_clear_logs(m_session->ctx);
-    }
+    onReplicas_([&](DeviceSession& d) {
+        if (d.ctx) {
+            wn_set_momentum(d.ctx, m_momentum.memptr(), (int)m_momentum.n_elem);
+            wn_clear_logs(d.ctx);
+        }
+        return true;
+    });
 }
 
 /// High-level cost method(s).
@@ -595,7 +759,10 @@ void Wavenet::update_(const Col& gradient) {
     scaleMomentum_(effectiveInertia_(steps));
     addMomentum_(gradient * (-m_alpha));
     setFilter(m_filter + m_momentum);
-    if (m_session && m_session->ctx) wn_set_momentum(m_session->ctx, m_momentum.memptr(), (int)m_momentum.n_elem);
+    onReplicas_([&](DeviceSession& d) {
+        if (d.ctx) wn_set_momentum(d.ctx, m_momentum.memptr(), (int)m_momentum.n_elem);
+        return true;
+    });
 }
 
 }  // namespace wavenet
