@@ -1,0 +1,21 @@
+#!/bin/bash
+# SQ / TCC counter passes over one bench workload (one counter group per run), on the GPU box:
+#   tools/pmc_workload.sh <workload> <tag>      e.g. tools/pmc_workload.sh 1d1024 r02
+# The per-dispatch tables land in gpurun_out/pmc/<tag>_<workload>_<group>.csv.
+set -u
+W=$1
+TAG=$2
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/pmc
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+run() {
+  local name=$1; shift
+  rm -rf /tmp/pmc_$name
+  timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$name -o r -- python $ROOT/bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_${W}_$name.err || { echo "pass $name failed"; tail -5 $OUT/${TAG}_${W}_$name.err; exit 1; }
+  cp $(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1) $OUT/${TAG}_${W}_$name.csv
+  echo "pass $name done"
+}
+run fetch FETCH_SIZE && run write WRITE_SIZE \
+  && run sq1 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAVES SQ_INSTS_SMEM \
+  && run sq2 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM

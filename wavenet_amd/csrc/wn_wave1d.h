@@ -9,10 +9,14 @@
 // length, and fetches its taps from the lanes that hold them.  All filter arithmetic is
 // straight-line code on registers with compile-time indices; the low-pass pyramid of the backward
 // pass simply stays in registers (36 doubles).  LDS holds only the 1024 coefficients for the Gini
-// phase, which is the one of the workgroup-per-example kernels run by a single wave.
-//
-// Build switches for timing experiments (tools/build_variant.sh): W1D_SKIP_GINI, W1D_SKIP_BWD leave a
-// phase out (wrong results), W1D_WAVES sets the waves per SIMD the register budget is compiled for.
+// phase.  Its ranks come from a bitonic sort of the wave's 1024 keys, 16 per lane, in the manner of the
+// 64x64 kernel (wn_wave64.h): a key is |c| with its low 10 mantissa bits replaced by the coefficient's
+// index, so v_min_f64 / v_max_f64 carry the index along, keys are unique and equal magnitudes come out in
+// index order; compare-exchanges run on register bits only, and three register layouts (index bits 0-3,
+// 4-7 or 6-9 in the register number) exchanged through LDS bring every index bit into the registers.  An
+// example whose keys collide in their upper 54 bits (so that the order by index may differ from the order
+// by exact magnitude), or with magnitudes outside the range where the fast sign is exact, takes the general
+// Gini phase of the workgroup-per-example kernels instead, run by this one wave.
 #pragma once
 
 #include "wn_kernels.h"
@@ -236,19 +240,202 @@ __device__ __forceinline__ double w1d_bwd_small(double dlo, double dhi, double a
     return s;
 }
 
+
+// ---- Gini ranks of 1024 coefficients in one wave -------------------------------------------------------
+__device__ __forceinline__ void w1d_cmpx(double& lo, double& hi) {   // min -> lo, max -> hi
+    double mn, mx;
+    asm volatile("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(mn), "=&v"(mx) : "v"(lo), "v"(hi));
+    lo = mn;
+    hi = mx;
+}
+__device__ __forceinline__ void w1d_flip(double& k, unsigned mask) {
+    k = __hiloint2double(__double2hiint(k) ^ (int)mask, __double2loint(k));
+}
+// Position of sort index e in the exchange buffer: one double of padding per 16, which makes the three
+// layouts' accesses conflict-free.
+__device__ __forceinline__ constexpr int w1d_pos(int e) { return e + (e >> 4); }
+constexpr int W1D_SORT_DOUBLES = 1024 + 64;
+
+// Sort index of register r in lane `lane`: layout A (register = index bits 0-3), M (bits 4-7), B (bits 6-9).
+constexpr int W1D_LAYOUT_A = 0, W1D_LAYOUT_M = 4, W1D_LAYOUT_B = 6;
+template <int LAYOUT>
+__device__ __forceinline__ int w1d_index(int lane, int r) {
+    if constexpr (LAYOUT == W1D_LAYOUT_A) return 16 * lane + r;
+    else if constexpr (LAYOUT == W1D_LAYOUT_M) return 256 * (lane >> 4) + 16 * r + (lane & 15);
+    else return 64 * r + lane;
+}
+// No fence between the writes and the reads: both are accesses to doubles that may alias as far as the compiler
+// can tell, so it keeps their program order, and the LDS executes a wave's operations in order.  (A fence here
+// also keeps the key array from being held in registers.)
+template <int FROM, int TO>
+__device__ __forceinline__ void w1d_exchange(double (&k)[16], double* buf, int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) buf[w1d_pos(w1d_index<FROM>(lane, r))] = k[r];
+#pragma unroll
+    for (int r = 0; r < 16; r++) k[r] = buf[w1d_pos(w1d_index<TO>(lane, r))];
+}
+// compare-exchanges on index bits HI .. LO, which are register bits HI - BASE .. LO - BASE in the current layout
+template <int BASE, int HI, int LO>
+__device__ __forceinline__ void w1d_substages(double (&k)[16]) {
+    constexpr int RB = HI - BASE;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        if (!(r & (1 << RB))) w1d_cmpx(k[r], k[r | (1 << RB)]);
+    }
+    if constexpr (HI > LO) w1d_substages<BASE, HI - 1, LO>(k);
+}
+// Merge step KK of the bitonic sort (blocks of 2^KK); on entry and exit the keys are in layout A.  A key is held
+// negated while its block sorts descending, i.e. while bit KK of its index is set, so every compare-exchange
+// is minimum -> lower index.
+template <int KK>
+__device__ __forceinline__ void w1d_merge(double (&k)[16], double* buf, int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int e = 16 * lane + r;
+        // negated so far: where bit KK - 1 is set (nowhere before the first merge); from now on: where bit KK is set
+        // (bit 10 is 0: the last merge ends with every key positive)
+        // (an exclusive-or with a mask rather than a branch on the lane number)
+        const int was = (KK > 1) ? (e >> (KK - 1)) & 1 : 0, now = (e >> KK) & 1;
+        w1d_flip(k[r], (unsigned)(was ^ now) << 31);
+    }
+    if constexpr (KK <= 4) {
+        w1d_substages<W1D_LAYOUT_A, KK - 1, 0>(k);
+    } else if constexpr (KK <= 8) {
+        w1d_exchange<W1D_LAYOUT_A, W1D_LAYOUT_M>(k, buf, lane);
+        w1d_substages<W1D_LAYOUT_M, KK - 1, 4>(k);
+        w1d_exchange<W1D_LAYOUT_M, W1D_LAYOUT_A>(k, buf, lane);
+        w1d_substages<W1D_LAYOUT_A, 3, 0>(k);
+    } else {
+        w1d_exchange<W1D_LAYOUT_A, W1D_LAYOUT_B>(k, buf, lane);
+        w1d_substages<W1D_LAYOUT_B, KK - 1, 8>(k);
+        w1d_exchange<W1D_LAYOUT_B, W1D_LAYOUT_M>(k, buf, lane);
+        w1d_substages<W1D_LAYOUT_M, 7, 4>(k);
+        w1d_exchange<W1D_LAYOUT_M, W1D_LAYOUT_A>(k, buf, lane);
+        w1d_substages<W1D_LAYOUT_A, 3, 0>(k);
+    }
+    if constexpr (KK < 10) w1d_merge<KK + 1>(k, buf, lane);
+}
+
+// Coefficient index of the lane's slot s: slots 0-7 the top level's high-pass values (512 + 8 lane + s), 8-11 the
+// next level (256 + 4 lane + ..), 12-13 (128 + 2 lane + ..), 14 (64 + lane), 15 the levels below (lane).
+__device__ __forceinline__ int w1d_coef_index(int lane, int s) {
+    return s < 8 ? 512 + 8 * lane + s : s < 12 ? 256 + 4 * lane + (s - 8) : s < 14 ? 128 + 2 * lane + (s - 12) : s == 14 ? 64 + lane : lane;
+}
+
+// Gini term and gradient (src/CostFunctions.cxx:6-37, 49-105) from the coefficients in registers, y[s] the
+// coefficient of index w1d_coef_index(lane, s).  Leaves the errors in bufY[0 .. 1024) in coefficient order and
+// returns true -- or returns false without having touched y when the example needs the general path.
+// buf: W1D_SORT_DOUBLES doubles (may be bufY itself); rk: 1024 16-bit words.
+__device__ __forceinline__ bool w1d_gini_fast(const double (&y)[16], double* buf, unsigned short* rk, double* bufY, int lane,
+                                              double* S_out) {
+    constexpr int n = 1024;
+    // the index-in-the-mantissa keys need magnitudes that are zero or normal numbers, the fast sign magnitudes
+    // for which x / sqrt(x * x) is exactly +-1
+    bool odd = false;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const double ay = __builtin_fabs(y[s]);
+        odd |= !((ay == 0.0) | ((ay >= 0x1p-500) & (ay <= 0x1p500)));
+    }
+    if (__any(odd)) return false;
+    double k[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const double ay = __builtin_fabs(y[s]);
+        const unsigned idx = (unsigned)w1d_coef_index(lane, s);
+        k[s] = __hiloint2double(__double2hiint(ay), (int)((((unsigned)__double2loint(ay)) & ~0x3FFu) | idx));
+    }
+    w1d_merge<1>(k, buf, lane);
+    // sorted position p = 16 lane + r; keys that agree in their upper 54 bits (zeros aside) would have to be ordered
+    // by their exact low bits: leave those examples to the general path
+    bool same = false;
+    {
+        const double prev_last = __shfl_up(k[15], 1, 64);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const unsigned long long kb = (unsigned long long)__double_as_longlong(k[r]);
+            const unsigned long long pb = (unsigned long long)__double_as_longlong((r > 0) ? k[r - 1] : prev_last);
+            same |= ((pb ^ kb) < 1024ull) & (kb >= 1024ull) & ((r > 0) | (lane > 0));
+        }
+    }
+    if (__any(same)) return false;
+#pragma unroll
+    for (int r = 0; r < 16; r++) rk[(unsigned)__double2loint(k[r]) & 0x3FFu] = (unsigned short)(16 * lane + r + 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // the ranks of the lane's own coefficients: contiguous per level
+    unsigned rank[16];
+    {
+        const uint4 r8 = *reinterpret_cast<const uint4*>(rk + 512 + 8 * lane);
+        const uint2 r4 = *reinterpret_cast<const uint2*>(rk + 256 + 4 * lane);
+        const unsigned r2 = *reinterpret_cast<const unsigned*>(rk + 128 + 2 * lane);
+        const unsigned w8[4] = {r8.x, r8.y, r8.z, r8.w};
+#pragma unroll
+        for (int s = 0; s < 8; s++) rank[s] = (w8[s >> 1] >> (16 * (s & 1))) & 0xFFFFu;
+        rank[8] = r4.x & 0xFFFFu; rank[9] = r4.x >> 16; rank[10] = r4.y & 0xFFFFu; rank[11] = r4.y >> 16;
+        rank[12] = r2 & 0xFFFFu; rank[13] = r2 >> 16;
+        rank[14] = rk[64 + lane];
+        rank[15] = rk[lane];
+    }
+    double f = 0, sabs = 0;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const double coef = 2.0 * (double)rank[s] - (double)n - 1.0;
+        const double ay = __builtin_fabs(y[s]);
+        f = __builtin_fma(coef, ay, f);
+        sabs += ay;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        f += __shfl_xor(f, off, 64);
+        sabs += __shfl_xor(sabs, off, 64);
+    }
+    const double g = (double)n * sabs;
+    const double inv_g2 = 1.0 / (g * g);
+    double d[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const double coef = 2.0 * (double)rank[s] - (double)n - 1.0;
+        const double sg = (y[s] == 0.0) ? 0.0 : __builtin_copysign(1.0, y[s]);   // == sign_ref in this range
+        d[s] = -((coef * sg) * g - f * ((double)n * sg)) * inv_g2;
+    }
+    // (the exchange buffer may be bufY: the sort is over)
+    {
+        double2* t8 = reinterpret_cast<double2*>(bufY + 512 + 8 * lane);
+#pragma unroll
+        for (int m = 0; m < 4; m++) t8[m] = make_double2(d[2 * m], d[2 * m + 1]);
+        double2* t4 = reinterpret_cast<double2*>(bufY + 256 + 4 * lane);
+        t4[0] = make_double2(d[8], d[9]);
+        t4[1] = make_double2(d[10], d[11]);
+        *reinterpret_cast<double2*>(bufY + 128 + 2 * lane) = make_double2(d[12], d[13]);
+        bufY[64 + lane] = d[14];
+        bufY[lane] = d[15];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    *S_out = 1.0 - f / g;
+    return true;
+}
+
+// The general Gini phase as a call of its own: inlined, its registers would add to those the fast path holds.
+__device__ __attribute__((noinline)) double w1d_gini_general(double* bufY, double* red, int* flag, int lane) {
+    return gini_phase<64, 4, true>(bufY, 1024, red, flag, lane);
+}
+
 // ---- kernel -------------------------------------------------------------------------------------------
 // 64 threads = one wave = one example in flight per workgroup; grid-stride over the batch.
 #ifndef W1D_WAVES
-#define W1D_WAVES (NP > 16 ? 1 : 2)
+#define W1D_WAVES (NP >= 16 ? 1 : 2)
 #endif
 template <int NP>
 __global__ __launch_bounds__(64, W1D_WAVES) void k_train1d1024(FusedArgs A) {
     constexpr int n = 1024;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* bufY = smem;                       // 1024 coefficients / sort slots / errors
-    double* red = bufY + n;                    // scratch of the Gini phase
+    double* bufY = smem;                       // sort exchange buffer; 1024 coefficients / errors in coefficient order
+    unsigned short* rk = reinterpret_cast<unsigned short*>(bufY + W1D_SORT_DOUBLES);   // ranks by coefficient index
+    double* red = bufY + W1D_SORT_DOUBLES + 256;    // scratch of the general Gini phase
     int* flag = reinterpret_cast<int*>(red + 4);
-    const int lane = threadIdx.x;
+    const int lane0 = threadIdx.x;
     const FilterDev* filt = A.filt;
     double a[NP], b[NP];
 #pragma unroll
@@ -262,6 +449,10 @@ __global__ __launch_bounds__(64, W1D_WAVES) void k_train1d1024(FusedArgs A) {
 
     double accG = 0, accS = 0, accBad = 0;
     for (int e = blockIdx.x; e < A.B; e += gridDim.x) {
+        // The lane number as a value the compiler cannot see through: the LDS and cross-lane addresses derived
+        // from it are then computed where they are used, not all held in registers across the whole loop.
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
         // ---- forward
         double x[16], lo9[8], lo8[4], lo7[2], lo6[1], hi[8];
         {
@@ -270,63 +461,67 @@ __global__ __launch_bounds__(64, W1D_WAVES) void k_train1d1024(FusedArgs A) {
             for (int i = 0; i < 8; i++) { const double2 t = src[i]; x[2 * i] = t.x; x[2 * i + 1] = t.y; }
         }
         __syncthreads();   // the previous example's errors have been read
+        double y[16];      // the lane's coefficients, slot s = coefficient w1d_coef_index(lane, s)
         w1d_fwd_block<NP, 16>(x, lo9, hi, a, b, lane);
 #pragma unroll
-        for (int m = 0; m < 8; m++) bufY[512 + 8 * lane + m] = hi[m];
+        for (int m = 0; m < 8; m++) y[m] = hi[m];
         {
             double h8[4];
             w1d_fwd_block<NP, 8>(lo9, lo8, h8, a, b, lane);
 #pragma unroll
-            for (int m = 0; m < 4; m++) bufY[256 + 4 * lane + m] = h8[m];
+            for (int m = 0; m < 4; m++) y[8 + m] = h8[m];
             double h7[2];
             w1d_fwd_block<NP, 4>(lo8, lo7, h7, a, b, lane);
-            bufY[128 + 2 * lane] = h7[0];
-            bufY[128 + 2 * lane + 1] = h7[1];
+            y[12] = h7[0];
+            y[13] = h7[1];
             double h6[1];
             w1d_fwd_block<NP, 2>(lo7, lo6, h6, a, b, lane);
-            bufY[64 + lane] = h6[0];
+            y[14] = h6[0];
         }
         // levels below 64 values, replicated: los[i] = low-pass level i at index lane mod 2^i
-        double los[6], his;
+        double los[6], his, small = 0;
         w1d_fwd_small<NP, 5>(lo6[0], los[5], his, a, b, lane);
-        if (lane >= 32) bufY[lane] = his;                  // coefficient 32 + k sits in lane 32 + k
+        if (lane >= 32) small = his;                       // coefficient 32 + k sits in lane 32 + k
         w1d_fwd_small<NP, 4>(los[5], los[4], his, a, b, lane);
-        if (lane >= 16 && lane < 32) bufY[lane] = his;
+        if (lane >= 16 && lane < 32) small = his;
         w1d_fwd_small<NP, 3>(los[4], los[3], his, a, b, lane);
-        if (lane >= 8 && lane < 16) bufY[lane] = his;
+        if (lane >= 8 && lane < 16) small = his;
         w1d_fwd_small<NP, 2>(los[3], los[2], his, a, b, lane);
-        if (lane >= 4 && lane < 8) bufY[lane] = his;
+        if (lane >= 4 && lane < 8) small = his;
         w1d_fwd_small<NP, 1>(los[2], los[1], his, a, b, lane);
-        if (lane >= 2 && lane < 4) bufY[lane] = his;
+        if (lane >= 2 && lane < 4) small = his;
         w1d_fwd_small<NP, 0>(los[1], los[0], his, a, b, lane);
-        if (lane == 1) bufY[1] = his;
-        if (lane == 0) bufY[0] = los[0];
-        __syncthreads();
+        if (lane == 1) small = his;
+        if (lane == 0) small = los[0];
+        y[15] = small;
 
-        // ---- Gini term and its gradient, in place (src/CostFunctions.cxx:6-37, 49-105)
-#ifdef W1D_SKIP_GINI
-        const double S = 1.0;
-#else
-        const double S = gini_phase<64, 4, true>(bufY, n, red, flag, lane);
-#endif
+        // ---- Gini term and its gradient (src/CostFunctions.cxx:6-37, 49-105): errors to bufY in coefficient order
+        double S;
+        if (!w1d_gini_fast(y, bufY, rk, bufY, lane, &S)) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) bufY[512 + 8 * lane + m] = y[m];
+#pragma unroll
+            for (int m = 0; m < 4; m++) bufY[256 + 4 * lane + m] = y[8 + m];
+            bufY[128 + 2 * lane] = y[12];
+            bufY[128 + 2 * lane + 1] = y[13];
+            bufY[64 + lane] = y[14];
+            bufY[lane] = y[15];
+            __syncthreads();
+            S = w1d_gini_general(bufY, red, flag, lane);
+        }
 
         // ---- backward
         double gL[NP], gH[NP];
 #pragma unroll
         for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
-#ifndef W1D_SKIP_BWD
-        // For the shorter filters the signal is read again for the last level rather than held in
-        // registers through the Gini phase (measured: faster up to 8 taps, slower at 16).
+        // the signal is read again for the last level rather than held in registers through the Gini phase
         double xb[16];
-        if constexpr (NP <= 8) {
+        {
             const double* again = A.X + (size_t)e * n + 16 * lane;
             asm volatile("" : "+v"(again));
             const double2* src = reinterpret_cast<const double2*>(again);
 #pragma unroll
             for (int i = 0; i < 8; i++) { const double2 t = src[i]; xb[2 * i] = t.x; xb[2 * i + 1] = t.y; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; i++) xb[i] = x[i];
         }
         double d = bufY[0];                                                                      // errors on lo_0
         d = w1d_bwd_small<NP, 0>(d, bufY[1], los[1], a, b, gL, gH, lane);                        // -> 2 values
@@ -346,9 +541,6 @@ __global__ __launch_bounds__(64, W1D_WAVES) void k_train1d1024(FusedArgs A) {
         for (int m = 0; m < 8; m++) h8[m] = bufY[512 + 8 * lane + m];
         w1d_bwd_block<NP, 8, false>(d8, h8, xb, unused, a, b, gL, gH, lane);
 
-#else
-        gL[0] = bufY[lane];
-#endif
         // tap k' collects gL[k'] and sH[k'] gH[NP-1-k'], summed over the 64 lanes
         double mine = 0;
 #pragma unroll
@@ -374,9 +566,9 @@ __global__ __launch_bounds__(64, W1D_WAVES) void k_train1d1024(FusedArgs A) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, 64);
     double* part = A.partial + (size_t)blockIdx.x * PSTRIDE;
-    const int k = lane - dpad;
-    if (lane < NP && k >= 0 && k < N) part[k] = accG;
-    if (lane == 0) { part[N] = accS; part[N + 1] = bad; }
+    const int k = lane0 - dpad;
+    if (lane0 < NP && k >= 0 && k < N) part[k] = accG;
+    if (lane0 == 0) { part[N] = accS; part[N + 1] = bad; }
 }
 
 }  // namespace wn
