@@ -37,6 +37,7 @@ struct StepTail {
 
 struct UpdateShared {
     double a[MAXTAPS], b[MAXTAPS], prefA[MAXTAPS + 1], prefB[MAXTAPS + 1], anew[MAXTAPS], pnew[MAXTAPS], cost;
+    double apad[3 * MAXTAPS];   // a with a margin of zeros on either side
     float devA[MAXTAPS + 1], devB[MAXTAPS + 1];
     int bad;
 };
@@ -45,14 +46,49 @@ struct UpdateShared {
 // with its own use of it by then)
 constexpr int TAIL_LDS_BYTES = 16 + (MAXTAPS + 2) * 8 + (int)sizeof(UpdateShared) + 16;
 
-__device__ inline void write_padded_filter(FilterDev* f, const double* a) {
-    const int N = f->N, d = f->d;
-    for (int j = 0; j < MAXTAPS; j++) { f->a[j] = 0; f->b[j] = 0; }
-    for (int j = 0; j < N; j++) {
-        f->a_true[j] = a[j];
-        f->a[j + d] = a[j];
-        f->b[j + d] = parity_sign(j) * a[N - 1 - j];
+// The loops of the regularisation terms (wn_costfn.h) for operands in LDS.  This code runs once per step in a
+// single wave, so it pays both for LDS round trips that wait on each other and for every instruction it has
+// (fetched cold): the loops are kept as loops, unrolled by four with the loads of an unrolled group issued
+// together, and the additions keep the order (and so the rounding) of the plain loops.
+
+// lag_prefactor and lag_deviation_sq_float of lag m from one set of loads
+__device__ __forceinline__ void lag_sums(const double* v, int N, int m, double& prefactor, float& dev_sq) {
+    double pf = 0.;
+    float term = 0.f;
+    // k + 2m inside the filter: k from max(0, -2m) to min(N, N - 2m) - 1
+    const int k0 = m < 0 ? -2 * m : 0, k1 = m > 0 ? N - 2 * m : N;
+#pragma unroll 4
+    for (int k = k0; k < k1; k++) {
+        const double x = v[k] * v[k + 2 * m];
+        pf += x;
+        term = (float)((double)term + x);
     }
+    pf -= (m == 0 ? 1. : 0);
+    prefactor = pf * 2.;
+    const float dev = term - (m == 0 ? 1.f : 0.f);
+    dev_sq = dev * dev;
+}
+
+__device__ __forceinline__ double sum_taps_lds(const double* v, int N) {
+    double s = 0;
+#pragma unroll 4
+    for (int i = 0; i < N; i++) s += v[i];
+    return s;
+}
+
+// regd += sum over the lags l of pref[l] * lag_inner(a, N, t, l - N/2), in the order of the lags; a is read
+// through a zero margin (apad[i] = a[i - MAXTAPS] inside the filter, 0 outside), which is what skipping the
+// taps outside the filter amounts to: 0 + x and x + 0 are x
+__device__ __forceinline__ double add_lag_terms(double regd, const double* pref, const double* apad, int N, int t) {
+#pragma unroll 4
+    for (int l = 0; l <= N; l++) {
+        const int m = l - N / 2;
+        double inner = 0;
+        inner += apad[MAXTAPS + t + 2 * m];
+        inner += apad[MAXTAPS + t - 2 * m];
+        regd += pref[l] * inner;
+    }
+    return regd;
 }
 
 // Wavenet::flushBatchQueue_ / update_ / setFilter (src/Wavenet.cxx:717-765, 8-36) from the batch's sums.
@@ -63,51 +99,56 @@ __device__ inline void write_padded_filter(FilterDev* f, const double* a) {
 // stays up until the host takes it down.
 __device__ inline void update_body(FilterDev* f, const double* sums, const UpdateParams& P, UpdateShared& sh, int t) {
     const int N = f->N;
-    if (t == 0) sh.bad = f->nonfinite;
+    // everything the update reads from memory, in one round trip
+    const int was_bad = f->nonfinite, steps = f->steps, dpad = f->d;
+    const double a_mine = (t < N) ? f->a_true[t] : 0.0, p_mine = (t < N) ? f->momentum[t] : 0.0;
+    const double a_margin = (t >= MAXTAPS && t < MAXTAPS + N) ? f->a_true[t - MAXTAPS] : 0.0;
+    if (t == 0) sh.bad = was_bad;
     __syncthreads();
     if (t < 64) {
         const bool bad_here = (t <= N && !isfinite(sums[t])) || (t == N + 1 && sums[t] != 0.0);
         if (bad_here) sh.bad = 1;
-        if (t < N) sh.a[t] = f->a_true[t];
+        if (t < N) sh.a[t] = a_mine;
+        sh.apad[t] = a_margin;
+        if (t < MAXTAPS) sh.apad[64 + t] = 0.0;
     }
     __syncthreads();
     if (t < N) sh.b[t] = parity_sign(t) * sh.a[N - t - 1];
     __syncthreads();
     if (t <= N && !sh.bad) {
         const int m = t - N / 2;
-        sh.prefA[t] = lag_prefactor(sh.a, N, m);
-        sh.devA[t] = lag_deviation_sq_float(sh.a, N, m);
-        sh.prefB[t] = lag_prefactor(sh.b, N, m);
-        sh.devB[t] = lag_deviation_sq_float(sh.b, N, m);
+        lag_sums(sh.a, N, m, sh.prefA[t], sh.devA[t]);
+        lag_sums(sh.b, N, m, sh.prefB[t], sh.devB[t]);
     }
     __syncthreads();
     if (t < 64 && !sh.bad) {
-        const double suma = sum_taps(sh.a, N), sumb = sum_taps(sh.b, N);
+        const double suma = sum_taps_lds(sh.a, N), sumb = sum_taps_lds(sh.b, N);
         if (t < N) {
-            double regd = 0;                                                            // RegTermDeriv, tap t
-            for (int l = 0; l <= N; l++) regd += sh.prefA[l] * lag_inner(sh.a, N, t, l - N / 2);
+            double regd = add_lag_terms(0., sh.prefA, sh.apad, N, t);                    // RegTermDeriv, tap t
             if (P.wavelet) {
                 regd += 2 * (suma - 1.4142135623730951) * 1.0;
-                for (int l = 0; l <= N; l++) regd += sh.prefB[l] * lag_inner(sh.a, N, t, l - N / 2);
+                regd = add_lag_terms(regd, sh.prefB, sh.apad, N, t);
                 regd += 2 * (sumb - 0) * parity_sign(N - t - 1);
             }
             double gbar = sums[t] + P.lambda_sum * regd;
             gbar /= P.Bf;                                 // gradient /= float(size)          :727
-            double p = f->momentum[t] * P.inertia_eff;    // scaleMomentum_                    :760
+            double p = p_mine * P.inertia_eff;            // scaleMomentum_                    :760
             p += -P.alpha * gbar;                         // addMomentum_                      :761
             sh.pnew[t] = p;
             sh.anew[t] = sh.a[t] + p;                     // setFilter(m_filter + m_momentum)  :762
         }
         if (t == 0) {
             double reg = 0.;                                                            // RegTerm
-            float R2 = 0.f;
-            for (int l = 0; l <= N; l++) R2 = R2 + sh.devA[l];
+            float R2 = 0.f, R3 = 0.f;
+#pragma unroll 4
+            for (int l = 0; l <= N; l++) {
+                R2 = R2 + sh.devA[l];
+                R3 = R3 + sh.devB[l];
+            }
             reg += R2;
             if (P.wavelet) {
                 const double c1 = suma - 1.4142135623730951;
                 reg += c1 * c1;
-                float R3 = 0.f;
-                for (int l = 0; l <= N; l++) R3 = R3 + sh.devB[l];
                 reg += R3;
                 reg += sumb * sumb;
             }
@@ -123,13 +164,22 @@ __device__ inline void update_body(FilterDev* f, const double* sums, const Updat
         if (t == 0) f->nonfinite = 1;
         return;
     }
-    if (t < N) f->momentum[t] = sh.pnew[t];
+    // the new state: lane j writes entry j of the padded taps, of the plain filter, of the momentum and of the log
+    const int idx = steps % P.cap;
+    if (t < MAXTAPS) {
+        const int j = t - dpad;
+        const bool real = (j >= 0) & (j < N);
+        f->a[t] = real ? sh.anew[real ? j : 0] : 0.0;
+        f->b[t] = real ? parity_sign(j) * sh.anew[real ? N - 1 - j : 0] : 0.0;
+        if (t < N) {
+            f->a_true[t] = sh.anew[t];
+            f->momentum[t] = sh.pnew[t];
+        }
+        P.logF[(size_t)idx * MAXTAPS + t] = (t < N) ? sh.anew[t] : 0.0;
+    }
     if (t == 0) {
-        const int idx = f->steps % P.cap;
         P.logC[idx] = sh.cost;
-        f->steps = f->steps + 1;
-        for (int k = 0; k < MAXTAPS; k++) P.logF[(size_t)idx * MAXTAPS + k] = (k < N) ? sh.anew[k] : 0.0;
-        write_padded_filter(f, sh.anew);
+        f->steps = steps + 1;
     }
 }
 
