@@ -64,6 +64,54 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Sums over the wave's lanes of M values per lane at once (M a power of two, at most 64): returns, in lane l, the
+// sum over all lanes of v[l % M].  Butterfly steps at distances of M and more add all M values; below that a
+// lane keeps the half of its values that its own lane bit selects and hands the other half to its partner, so
+// the steps move M/2, M/4, ... 1 values -- M - 1 exchanges in all instead of 6 M for M separate sums.
+// v is destroyed.  A fixed order.
+template <int M, int OFF>
+__device__ __forceinline__ void wave_sum_scatter_step(double (&v)[M], int lane) {
+    if constexpr (OFF >= M) {
+#pragma unroll
+        for (int i = 0; i < M; i++) v[i] += __shfl_xor(v[i], OFF, 64);
+    } else {
+        const bool up = (lane & OFF) != 0;
+#pragma unroll
+        for (int i = 0; i < OFF; i++) {
+            const double keep = up ? v[i + OFF] : v[i];
+            const double send = up ? v[i] : v[i + OFF];
+            v[i] = keep + __shfl_xor(send, OFF, 64);
+        }
+    }
+    if constexpr (OFF > 1) wave_sum_scatter_step<M, OFF / 2>(v, lane);
+}
+template <int M>
+__device__ __forceinline__ double wave_sum_scatter(double (&v)[M], int lane) {
+    static_assert(M >= 1 && M <= 64 && (M & (M - 1)) == 0, "a power of two up to the wave size");
+    wave_sum_scatter_step<M, 32>(v, lane);
+    return v[0];
+}
+
+// The window sums gL[NP], gH[NP] of every thread added up over the workgroup of T threads: thread t < 2 NP receives
+// the sum of gL[t] (t < NP) or gH[t - NP]; the others receive 0.  red: (T / 64) * 2 NP doubles of LDS.  Contains barriers.
+template <int NP, int T>
+__device__ __forceinline__ double block_window_sums(const double (&gL)[NP], const double (&gH)[NP], double* red, int tid) {
+    double v[2 * NP];
+#pragma unroll
+    for (int u = 0; u < NP; u++) { v[u] = gL[u]; v[NP + u] = gH[u]; }
+    const int lane = tid & 63;
+    const double mine = wave_sum_scatter<2 * NP>(v, lane);
+    __syncthreads();
+    if (lane < 2 * NP) red[(tid >> 6) * 2 * NP + lane] = mine;
+    __syncthreads();
+    double s = 0;
+    if (tid < 2 * NP) {
+#pragma unroll
+        for (int wv = 0; wv < T / 64; wv++) s += red[wv * 2 * NP + tid];
+    }
+    return s;
+}
+
 // Sum of one value per thread over the workgroup, same result in every thread.
 // Fixed order: lanes by shuffle tree, waves in index order.  `red` needs T/64 doubles.
 template <int T>

@@ -94,11 +94,12 @@ __global__ void kb_finish_pass(double* out, double* P, size_t xs, Geom g) {
 }
 
 // Filter-gradient correlation of one level (see bwd_level in wn_device.h for the indexing).
-// partial[(example * GXMAX + workgroup) * 2NP + u] accumulates over the launches of one backward.
+// partial[(example * pgx + workgroup) * 2NP + u] accumulates over the launches of one backward (pgx: slots per
+// example, GXMAX unless the chunk has so few examples that more workgroups per example are needed to fill the chip).
 template <int NP>
 __global__ __launch_bounds__(BT) void kb_grad_level(const double* __restrict__ lp, const double* __restrict__ hp,
                                                     const double* __restrict__ act, size_t xs, Geom g, int lgLen,
-                                                    double* partial) {
+                                                    double* partial, int pgx) {
     __shared__ double red[(BT / 64) * 2 * NP];
     double gL[NP], gH[NP];
 #pragma unroll
@@ -120,18 +121,8 @@ __global__ __launch_bounds__(BT) void kb_grad_level(const double* __restrict__ l
         }
     }
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int u = 0; u < NP; u++) {
-        const double sl = wave_sum(gL[u]), sh = wave_sum(gH[u]);
-        if ((tid & 63) == 0) { red[(tid >> 6) * 2 * NP + u] = sl; red[(tid >> 6) * 2 * NP + NP + u] = sh; }
-    }
-    __syncthreads();
-    if (tid < 2 * NP) {
-        double s = 0;
-#pragma unroll
-        for (int wv = 0; wv < BT / 64; wv++) s += red[wv * 2 * NP + tid];
-        partial[((size_t)blockIdx.y * GXMAX + blockIdx.x) * 2 * NP + tid] += s;
-    }
+    const double s = block_window_sums<NP, BT>(gL, gH, red, tid);
+    if (tid < 2 * NP) partial[((size_t)blockIdx.y * pgx + blockIdx.x) * 2 * NP + tid] += s;
 }
 
 // out[c] = sum over (r, j) with (N/2 + 2r - j) mod 2len == c of a[j] lp[r] + b[j] hp[r]
@@ -170,7 +161,7 @@ __global__ __launch_bounds__(BT) void kb_prop_level(const double* __restrict__ l
 template <int NP>
 __global__ __launch_bounds__(BT) void kb_bwd_level(const double* __restrict__ lp, const double* __restrict__ hp,
                                                    const double* __restrict__ act, double* __restrict__ out, size_t xs, Geom g,
-                                                   int lgLen, const FilterDev* filt, double* partial) {
+                                                   int lgLen, const FilterDev* filt, double* partial, int pgx) {
     __shared__ double red[(BT / 64) * 2 * NP];
     double a[NP], b[NP];
 #pragma unroll
@@ -210,18 +201,8 @@ __global__ __launch_bounds__(BT) void kb_bwd_level(const double* __restrict__ lp
         out[lo + (size_t)(2 * r + 1) * g.es] = so;
     }
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int u = 0; u < NP; u++) {
-        const double sl = wave_sum(gL[u]), sh = wave_sum(gH[u]);
-        if ((tid & 63) == 0) { red[(tid >> 6) * 2 * NP + u] = sl; red[(tid >> 6) * 2 * NP + NP + u] = sh; }
-    }
-    __syncthreads();
-    if (tid < 2 * NP) {
-        double s = 0;
-#pragma unroll
-        for (int wv = 0; wv < BT / 64; wv++) s += red[wv * 2 * NP + tid];
-        partial[((size_t)blockIdx.y * GXMAX + blockIdx.x) * 2 * NP + tid] += s;
-    }
+    const double s = block_window_sums<NP, BT>(gL, gH, red, tid);
+    if (tid < 2 * NP) partial[((size_t)blockIdx.y * pgx + blockIdx.x) * 2 * NP + tid] += s;
 }
 
 // ---- level kernels for contiguous lines, operands staged in LDS ------------------------------------------
@@ -275,18 +256,23 @@ __global__ __launch_bounds__(LT) void kb_fwd_level_lds(const double* __restrict_
 }
 
 // kb_bwd_level / kb_grad_level (PROP false) for contiguous lines with at least LT errors per line:
-// grid (workgroups per example <= GXMAX, examples); a workgroup walks over tiles of LT errors.
+// grid (workgroups per example <= pgx, examples); a workgroup walks over tiles of LT errors.  The operands of the
+// next tile are fetched into registers while the current one is worked on from LDS, so that a step does not
+// wait for a round trip to memory.
 template <int NP, bool PROP>
 __global__ __launch_bounds__(LT) void kb_bwd_level_lds(const double* __restrict__ lp, const double* __restrict__ hp,
                                                        const double* __restrict__ act, double* __restrict__ out, size_t xs, Geom g,
-                                                       int lgLen, const FilterDev* filt, double* partial) {
+                                                       int lgLen, const FilterDev* filt, double* partial, int pgx) {
     constexpr int S = NP / 2;
     constexpr int JE = S & 1, JO = (S + 1) & 1;
     constexpr int CE = (JE - S) / 2, CO = (1 + JO - S) / 2;
     constexpr int CMIN = CE < CO ? CE : CO;
-    constexpr int EW = LT + NP / 2 + 1;                  // errors a tile's propagation reads
-    __shared__ __attribute__((aligned(16))) double tile[2 * LT + NP];
-    __shared__ double tl[PROP ? EW : 1], th[PROP ? EW : 1];
+    constexpr int EW = PROP ? LT + NP / 2 + 1 : LT;      // errors a tile reads: with PROP those its propagation needs, from r0 + CMIN on
+    constexpr int E0 = PROP ? -CMIN : 0;                 // position of error r0 among them
+    constexpr int AW = 2 * LT + NP;                      // activations a tile reads
+    constexpr int NA = (AW + LT - 1) / LT, NE = (EW + LT - 1) / LT;
+    __shared__ __attribute__((aligned(16))) double tile[AW];
+    __shared__ double tl[EW], th[EW];
     __shared__ double red[(LT / 64) * 2 * NP];
     double a[NP], b[NP];
 #pragma unroll
@@ -295,20 +281,45 @@ __global__ __launch_bounds__(LT) void kb_bwd_level_lds(const double* __restrict_
 #pragma unroll
     for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
     const int tid = threadIdx.x;
-    const int W = 1 << (g.lgNL + lgLen), rmask = (1 << lgLen) - 1;
-    for (int w0 = blockIdx.x * LT; w0 < W; w0 += gridDim.x * LT) {
+    const int W = 1 << (g.lgNL + lgLen), rmask = (1 << lgLen) - 1, amask = (2 << lgLen) - 1;
+    double fa[NA], fl[NE], fh[NE];
+    auto fetch = [&](int w0) {
         const int line = w0 >> lgLen, r0 = w0 & rmask;
         const size_t off = (size_t)blockIdx.y * xs + (size_t)line * g.ls;
-        __syncthreads();
-        stage_window<NP>(tile, act + off, 2 * r0 + NP / 2 - (NP - 1), (2 << lgLen) - 1);
-        if constexpr (PROP) {
-            for (int t = tid; t < EW; t += LT) {
-                tl[t] = lp[off + ((r0 + CMIN + t) & rmask)];
-                th[t] = hp[off + ((r0 + CMIN + t) & rmask)];
-            }
+        const int first = 2 * r0 + NP / 2 - (NP - 1);
+#pragma unroll
+        for (int q = 0; q < NA; q++) {
+            const int t = tid + q * LT;
+            fa[q] = (t < AW) ? act[off + ((first + t) & amask)] : 0.0;
         }
-        __syncthreads();
-        const double dl = lp[off + r0 + tid], dh = hp[off + r0 + tid];
+#pragma unroll
+        for (int q = 0; q < NE; q++) {
+            const int t = tid + q * LT;
+            const bool on = t < EW;
+            fl[q] = on ? lp[off + ((r0 - E0 + t) & rmask)] : 0.0;
+            fh[q] = on ? hp[off + ((r0 - E0 + t) & rmask)] : 0.0;
+        }
+    };
+    int w0 = blockIdx.x * LT;
+    if (w0 < W) fetch(w0);
+    for (; w0 < W; w0 += gridDim.x * LT) {
+        const int line = w0 >> lgLen, r0 = w0 & rmask;
+        const size_t off = (size_t)blockIdx.y * xs + (size_t)line * g.ls;
+        rk::lds_barrier();       // the previous tile has been read (a barrier for LDS only: the store of its results may still be on its way)
+#pragma unroll
+        for (int q = 0; q < NA; q++) {
+            const int t = tid + q * LT;
+            if (t < AW) tile[t] = fa[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NE; q++) {
+            const int t = tid + q * LT;
+            if (t < EW) { tl[t] = fl[q]; th[t] = fh[q]; }
+        }
+        rk::lds_barrier();
+        const int wnext = w0 + gridDim.x * LT;
+        if (wnext < W) fetch(wnext);
+        const double dl = tl[E0 + tid], dh = th[E0 + tid];
         double win[NP];
         read_window<NP>(tile, win);
 #pragma unroll
@@ -328,18 +339,8 @@ __global__ __launch_bounds__(LT) void kb_bwd_level_lds(const double* __restrict_
             *reinterpret_cast<double2*>(out + off + 2 * (r0 + tid)) = make_double2(se, so);
         }
     }
-#pragma unroll
-    for (int u = 0; u < NP; u++) {
-        const double sl = wave_sum(gL[u]), sh = wave_sum(gH[u]);
-        if ((tid & 63) == 0) { red[(tid >> 6) * 2 * NP + u] = sl; red[(tid >> 6) * 2 * NP + NP + u] = sh; }
-    }
-    __syncthreads();
-    if (tid < 2 * NP) {
-        double s = 0;
-#pragma unroll
-        for (int wv = 0; wv < LT / 64; wv++) s += red[wv * 2 * NP + tid];
-        partial[((size_t)blockIdx.y * GXMAX + blockIdx.x) * 2 * NP + tid] += s;
-    }
+    const double s = block_window_sums<NP, LT>(gL, gH, red, tid);
+    if (tid < 2 * NP) partial[((size_t)blockIdx.y * pgx + blockIdx.x) * 2 * NP + tid] += s;
 }
 
 // ---- the levels below 4096 samples of a contiguous line in one launch ---------------------------------------
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(TAIL_T) void kb_fwd_tail(const double* __restrict__
 // workgroup walks over lines.
 template <int NP>
 __global__ __launch_bounds__(TAIL_T) void kb_bwd_tail(double* D, const double* act, const double* P, size_t xs, Geom g, int lgLen,
-                                                      const FilterDev* filt, double* partial) {
+                                                      const FilterDev* filt, double* partial, int pgx) {
     __shared__ double red[(TAIL_T / 64) * 2 * NP];
     double a[NP], b[NP];
 #pragma unroll
@@ -379,40 +380,90 @@ __global__ __launch_bounds__(TAIL_T) void kb_bwd_tail(double* D, const double* a
         __syncthreads();
         bwd_pass<NP, TAIL_T, (1 << TAIL_LG) / TAIL_T, true>(D + off, act + off, P + off, 1, 0, 0, lgLen, false, true, a, b, gL, gH, tid);
     }
+    const double s = block_window_sums<NP, TAIL_T>(gL, gH, red, tid);
+    if (tid < 2 * NP) partial[((size_t)blockIdx.y * pgx + blockIdx.x) * 2 * NP + tid] += s;
+}
+
+// The same two kernels with the line in LDS (samples, pyramid and coefficients / errors: 3 * 2^lgLen doubles of
+// dynamic LDS), for chunks with so few lines that a workgroup per line leaves most of the chip idle anyway:
+// every level is then an LDS round trip instead of a trip to the L2.  grid (lines, examples).
+constexpr int TAIL_LDS_T = 512;
+template <int NP>
+__global__ __launch_bounds__(TAIL_LDS_T) void kb_fwd_tail_lds(const double* __restrict__ in, double* P, double* out, size_t xs, Geom g,
+                                                              int lgLen, const FilterDev* filt) {
+    extern __shared__ __attribute__((aligned(16))) double tail_lds[];
+    const int len = 1 << lgLen, tid = threadIdx.x;
+    double* sIn = tail_lds;
+    double* sP = sIn + len;
+    double* sOut = sP + len;
+    double a[NP], b[NP];
 #pragma unroll
-    for (int u = 0; u < NP; u++) {
-        const double sl = wave_sum(gL[u]), sh = wave_sum(gH[u]);
-        if ((tid & 63) == 0) { red[(tid >> 6) * 2 * NP + u] = sl; red[(tid >> 6) * 2 * NP + NP + u] = sh; }
-    }
+    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    const size_t off = (size_t)blockIdx.y * xs + (size_t)blockIdx.x * g.ls;
+    for (int i = 2 * tid; i < len; i += 2 * TAIL_LDS_T) *reinterpret_cast<double2*>(sIn + i) = *reinterpret_cast<const double2*>(in + off + i);
     __syncthreads();
-    if (tid < 2 * NP) {
-        double s = 0;
-#pragma unroll
-        for (int wv = 0; wv < TAIL_T / 64; wv++) s += red[wv * 2 * NP + tid];
-        partial[((size_t)blockIdx.y * GXMAX + blockIdx.x) * 2 * NP + tid] += s;
+    fwd_pass<NP, TAIL_LDS_T>(sIn, sP, sOut, 1, 0, 0, lgLen, false, a, b, tid);
+    for (int i = 2 * tid; i < len; i += 2 * TAIL_LDS_T) {
+        *reinterpret_cast<double2*>(P + off + i) = *reinterpret_cast<const double2*>(sP + i);
+        *reinterpret_cast<double2*>(out + off + i) = *reinterpret_cast<const double2*>(sOut + i);
     }
 }
 
-// Per-example gradient from the per-workgroup window sums: tap k collects gL[k] and (-1)^(N-1-k) gH[N-1-k].
-__global__ void kb_grad_finish(const double* partial, int NP, const FilterDev* filt, double* grad_e) {
-    const int ex = blockIdx.x, kp = threadIdx.x;
-    if (kp >= NP) return;
-    double gl = 0, gh = 0;
-    for (int bx = 0; bx < GXMAX; bx++) {
-        const double* p = partial + ((size_t)ex * GXMAX + bx) * 2 * NP;
-        gl += p[kp];
-        gh += p[NP + (NP - 1 - kp)];
+template <int NP>
+__global__ __launch_bounds__(TAIL_LDS_T) void kb_bwd_tail_lds(double* D, const double* __restrict__ act, const double* __restrict__ P, size_t xs,
+                                                              Geom g, int lgLen, const FilterDev* filt, double* partial, int pgx) {
+    extern __shared__ __attribute__((aligned(16))) double tail_lds[];
+    __shared__ double red[(TAIL_LDS_T / 64) * 2 * NP];
+    const int len = 1 << lgLen, tid = threadIdx.x;
+    double* sD = tail_lds;
+    double* sAct = sD + len;
+    double* sP = sAct + len;
+    double a[NP], b[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    double gL[NP], gH[NP];
+#pragma unroll
+    for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
+    const size_t off = (size_t)blockIdx.y * xs + (size_t)blockIdx.x * g.ls;
+    for (int i = 2 * tid; i < len; i += 2 * TAIL_LDS_T) {
+        *reinterpret_cast<double2*>(sD + i) = *reinterpret_cast<const double2*>(D + off + i);
+        *reinterpret_cast<double2*>(sAct + i) = *reinterpret_cast<const double2*>(act + off + i);
+        *reinterpret_cast<double2*>(sP + i) = *reinterpret_cast<const double2*>(P + off + i);
     }
-    const int k = kp - filt->d;
-    if (k >= 0 && k < filt->N) grad_e[(size_t)ex * filt->N + k] = filt->vL[kp] * gl + filt->sH[kp] * gh;
+    __syncthreads();
+    bwd_pass<NP, TAIL_LDS_T, (1 << TAIL_LG) / TAIL_LDS_T, true>(sD, sAct, sP, 1, 0, 0, lgLen, false, true, a, b, gL, gH, tid);
+    for (int i = 2 * tid; i < len; i += 2 * TAIL_LDS_T) *reinterpret_cast<double2*>(D + off + i) = *reinterpret_cast<const double2*>(sD + i);
+    const double s = block_window_sums<NP, TAIL_LDS_T>(gL, gH, red, tid);
+    if (tid < 2 * NP) partial[((size_t)blockIdx.y * pgx + blockIdx.x) * 2 * NP + tid] += s;
+}
+
+// Per-example gradient from the per-workgroup window sums: tap k collects gL[k] and (-1)^(N-1-k) gH[N-1-k].
+// grid (examples), 256 threads: wave w takes taps w, w + 4, ...; lane l adds slots l, l + 64, ... in order and the
+// lanes are combined by a butterfly -- a fixed order.
+__global__ __launch_bounds__(256) void kb_grad_finish(const double* partial, int NP, const FilterDev* filt, double* grad_e, int pgx) {
+    const int ex = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int kp = wave; kp < NP; kp += 4) {
+        double gl = 0, gh = 0;
+        for (int bx = lane; bx < pgx; bx += 64) {
+            const double* p = partial + ((size_t)ex * pgx + bx) * 2 * NP;
+            gl += p[kp];
+            gh += p[NP + (NP - 1 - kp)];
+        }
+        gl = wave_sum(gl);
+        gh = wave_sum(gh);
+        const int k = kp - filt->d;
+        if (lane == 0 && k >= 0 && k < filt->N) grad_e[(size_t)ex * filt->N + k] = filt->vL[kp] * gl + filt->sH[kp] * gh;
+    }
 }
 
 // sums[0..N) += sum_e grad_e, sums[N] += sum_e S_e, sums[N+1] += number of non-finite values.  One wave per
 // quantity (grid N + 2): lane l adds examples l, l + 64, ... in order, the lanes are combined by a
 // butterfly -- a fixed order.
-__global__ __launch_bounds__(64) void kb_batch_sums(const double* grad_e, const double* S_e, int B, int N, double* sums, int first) {
+__global__ __launch_bounds__(64) void kb_batch_sums(const double* grad_e, const double* S_e, int B, int N, double* sums, int first,
+                                                    const unsigned* skip) {
     const int t = blockIdx.x, lane = threadIdx.x;
     if (t > N + 1) return;
+    if (skip && *skip) return;   // the chunk is going to be computed again (see train_impl): leave the sums alone
     double s = 0;
     if (t < N) {
         for (int e = lane; e < B; e += 64) s += grad_e[(size_t)e * N + t];
@@ -755,6 +806,11 @@ inline dim3 grid_for(int items, int B, int cap = 4096) {
 }
 
 // ---- passes ----------------------------------------------------------------------------------------------
+// the tail of the lines in LDS (kb_*_tail_lds) rather than through the L2: when the chunk has fewer lines than the chip
+// has CUs, and the tail is long enough for the levels' round trips to matter
+bool tail_in_lds(const wn_context* ctx, const Geom& g, int B, int lgTail) {
+    return ((long long)B << g.lgNL) <= ctx->numCU && lgTail >= 8 && lgTail <= TAIL_LG;
+}
 template <int NP>
 int fwd_pass_big(wn_context* ctx, const double* in, double* P, double* out, int B, size_t n, Geom g) {
     hipStream_t st = ctx->stream;
@@ -777,7 +833,13 @@ int fwd_pass_big(wn_context* ctx, const double* in, double* P, double* out, int 
     }
     if (tail) {
         const double* src = (tail == g.lgLen) ? in : P + ((size_t)1 << tail);
-        hipLaunchKernelGGL(kb_fwd_tail<NP>, dim3(1u << g.lgNL, B), dim3(TAIL_T), 0, st, src, P, out, n, g, tail, ctx->dfilt);
+        if (tail_in_lds(ctx, g, B, tail)) {
+            const size_t lds = (size_t)3 * sizeof(double) << tail;
+            WN_HIP(ctx, hipFuncSetAttribute((const void*)kb_fwd_tail_lds<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kb_fwd_tail_lds<NP>, dim3(1u << g.lgNL, B), dim3(TAIL_LDS_T), lds, st, src, P, out, n, g, tail, ctx->dfilt);
+        } else {
+            hipLaunchKernelGGL(kb_fwd_tail<NP>, dim3(1u << g.lgNL, B), dim3(TAIL_T), 0, st, src, P, out, n, g, tail, ctx->dfilt);
+        }
     } else {
         hipLaunchKernelGGL(kb_finish_pass, grid_for(1 << g.lgNL, B), dim3(BT), 0, st, out, P, n, g);
     }
@@ -790,7 +852,7 @@ int fwd_pass_big(wn_context* ctx, const double* in, double* P, double* out, int 
 // holding the errors on the input afterwards.  partial may be null (inverse transform: no gradient).
 template <int NP>
 int bwd_pass_big(wn_context* ctx, const double* coef, const double* in, const double* P, double* pingA,
-                 double* pingB, int B, size_t n, Geom g, bool lastPropagate, double* partial, const double** result,
+                 double* pingB, int B, size_t n, Geom g, bool lastPropagate, double* partial, int pgx, const double** result,
                  double* coefScratch = nullptr) {
     hipStream_t st = ctx->stream;
     const double* lp = coef;
@@ -802,36 +864,43 @@ int bwd_pass_big(wn_context* ctx, const double* coef, const double* in, const do
     if (coefScratch && partial && g.es == 1 && !g.lanesOnLines && ctx->wave64 && (g.lgLen > TAIL_LG || (NP <= 8 && lastPropagate))) {
         first = std::min(g.lgLen, TAIL_LG);
         const double* act = (first == g.lgLen) ? in : P + ((size_t)1 << first);
-        hipLaunchKernelGGL(kb_bwd_tail<NP>, dim3(std::min(1 << g.lgNL, GXMAX), B), dim3(TAIL_T), 0, st, coefScratch, act, P, n, g, first,
-                           ctx->dfilt, partial);
+        if (tail_in_lds(ctx, g, B, first) && (1 << g.lgNL) <= pgx) {
+            const size_t lds = (size_t)3 * sizeof(double) << first;
+            WN_HIP(ctx, hipFuncSetAttribute((const void*)kb_bwd_tail_lds<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kb_bwd_tail_lds<NP>, dim3(1u << g.lgNL, B), dim3(TAIL_LDS_T), lds, st, coefScratch, act, P, n, g, first,
+                               ctx->dfilt, partial, pgx);
+        } else {
+            hipLaunchKernelGGL(kb_bwd_tail<NP>, dim3(std::min(1 << g.lgNL, pgx), B), dim3(TAIL_T), 0, st, coefScratch, act, P, n, g, first,
+                               ctx->dfilt, partial, pgx);
+        }
     }
     for (int i = first; i < g.lgLen; i++) {
         const double* hp = coef + (size_t)(1 << i) * g.es;
         const bool propagate = (i != g.lgLen - 1 || lastPropagate);
         if (partial && NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && (1 << i) >= LT) {
             const double* act = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i);
-            const dim3 grid((unsigned)std::min<size_t>(((size_t)1 << (g.lgNL + i)) / LT, GXMAX), B);
+            const dim3 grid((unsigned)std::min<size_t>(((size_t)1 << (g.lgNL + i)) / LT, pgx), B);
             if (propagate) {
-                hipLaunchKernelGGL((kb_bwd_level_lds<NP, true>), grid, dim3(LT), 0, st, lp, hp, act, dst, n, g, i, ctx->dfilt, partial);
+                hipLaunchKernelGGL((kb_bwd_level_lds<NP, true>), grid, dim3(LT), 0, st, lp, hp, act, dst, n, g, i, ctx->dfilt, partial, pgx);
                 lp = dst;
                 dst = (dst == pingA) ? pingB : pingA;
             } else {
                 hipLaunchKernelGGL((kb_bwd_level_lds<NP, false>), grid, dim3(LT), 0, st, lp, hp, act, (double*)nullptr, n, g, i, ctx->dfilt,
-                                   partial);
+                                   partial, pgx);
             }
             continue;
         }
         if (partial && propagate) {
             const double* act = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i) * g.es;
-            hipLaunchKernelGGL(kb_bwd_level<NP>, grid_for(1 << (g.lgNL + i), B, GXMAX), dim3(BT), 0, st, lp, hp, act, dst, n, g, i,
-                               ctx->dfilt, partial);
+            hipLaunchKernelGGL(kb_bwd_level<NP>, grid_for(1 << (g.lgNL + i), B, pgx), dim3(BT), 0, st, lp, hp, act, dst, n, g, i,
+                               ctx->dfilt, partial, pgx);
             lp = dst;
             dst = (dst == pingA) ? pingB : pingA;
             continue;
         }
         if (partial) {
             const double* act = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i) * g.es;
-            hipLaunchKernelGGL(kb_grad_level<NP>, grid_for(1 << (g.lgNL + i), B, GXMAX), dim3(BT), 0, st, lp, hp, act, n, g, i, partial);
+            hipLaunchKernelGGL(kb_grad_level<NP>, grid_for(1 << (g.lgNL + i), B, pgx), dim3(BT), 0, st, lp, hp, act, n, g, i, partial, pgx);
         }
         if (i != g.lgLen - 1 || lastPropagate) {
             hipLaunchKernelGGL(kb_prop_level<NP>, grid_for(1 << (g.lgNL + i), B), dim3(BT), 0, st, lp, hp, dst, n, g, i, ctx->dfilt);
@@ -878,9 +947,10 @@ int gini_big(wn_context* ctx, const double* Y, double* D, int B, size_t n, doubl
 // Ranks by histogram and per-bucket LDS sort (wn_rank.h).  Leaves 32-bit ranks at home positions in keysB
 // (example e at (unsigned*)keysB + e * n), {f, g} in fg, the sparsity terms in S_e, and with D the errors.
 // *ok = false: some bucket would overflow (or the example is too long) -- nothing usable was written.
-// kmax: B words; kmax_ready: the producer of Y has raised them already.
+// kmax: B words, and 16 spare ones of which one serves as the give-up flag; kmax_ready: the producer of Y has raised
+// them already (and its caller zeroed all B + 16 words before that).
 int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB, unsigned* idxA,
-                 unsigned* idxB, double* fg, double* S_e, unsigned* kmax, bool kmax_ready, bool* ok) {
+                 unsigned* idxB, double* fg, double* S_e, unsigned* kmax, bool kmax_ready, bool* ok, const unsigned** pending = nullptr) {
     using namespace rk;
     *ok = false;
     int lgn = 0;
@@ -895,7 +965,7 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
     unsigned short* btab = reinterpret_cast<unsigned short*>(idxB + (size_t)B * NF);  // B * NF half words
     unsigned* rank = reinterpret_cast<unsigned*>(keysB);                              // B * n words
     unsigned* meta = rank + (size_t)B * n;                                            // B * meta_words(n) words
-    unsigned* flag = meta + (size_t)B * meta_words(n);
+    unsigned* flag = kmax + B + 4;   // beside the B words of kmax (the plan leaves 16 spare): nothing later in the chunk writes there
     unsigned long long* mag = reinterpret_cast<unsigned long long*>(keysA);
     static bool configured = false;
     if (!configured) {
@@ -909,22 +979,28 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
     int G = 1;
     while ((long long)G * B < 2LL * ctx->numCU && n / (2 * (size_t)G) >= (size_t)RK_TILE) G *= 2;
     if (!kmax_ready) {
-        WN_HIP(ctx, hipMemsetAsync(kmax, 0, (size_t)B * sizeof(unsigned), st));
+        // (the flag too: with kmax_ready the producer's caller has zeroed these B + 16 words before the producer ran)
+        WN_HIP(ctx, hipMemsetAsync(kmax, 0, (size_t)(B + 16) * sizeof(unsigned), st));
         hipLaunchKernelGGL(kr_max, dim3(G, B), dim3(RK_PT), 0, st, Y, n, kmax);
     }
     if (G > 1) WN_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)B * NF * sizeof(unsigned), st));
-    WN_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(unsigned), st));
     hipLaunchKernelGGL(kr_hist, dim3(G, B), dim3(RK_PT), (size_t)NF * 4, st, Y, n, kmax, hist, NF, lgBPO);
     hipLaunchKernelGGL(kr_scan, dim3(B), dim3(RK_BT), (size_t)NF * 4, st, hist, kmax, NF, lgBPO, n, btab, meta, flag);
     if (G == 1) hipLaunchKernelGGL(kr_part<true>, dim3(1, B), dim3(RK_PT), (size_t)NF * 2, st, Y, n, btab, meta, NF, lgBPO, mag, idxA, flag);
     else hipLaunchKernelGGL(kr_part<false>, dim3(G, B), dim3(RK_PT), (size_t)NF * 2, st, Y, n, btab, meta, NF, lgBPO, mag, idxA, flag);
     hipLaunchKernelGGL(kr_bucket, dim3((unsigned)nbmax * (((unsigned)B + 7u) & ~7u)), dim3(RK_KT), 0, st, mag, idxA, n, meta, rank, B, flag, NF, lgBPO);
-    hipLaunchKernelGGL(kr_finish, dim3((B + BT - 1) / BT), dim3(BT), 0, st, meta, n, B, fg, S_e);
+    hipLaunchKernelGGL(kr_finish, dim3(B), dim3(64), 0, st, meta, n, B, fg, S_e);
     WN_HIP(ctx, hipGetLastError());
-    unsigned over = 0;
-    WN_HIP(ctx, hipMemcpyAsync(&over, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    WN_HIP(ctx, hipStreamSynchronize(st));
-    if (over) return WN_OK;
+    if (pending) {
+        // the caller looks at the flag when it has queued everything that follows, and starts over if it is up; what the
+        // kernels in between compute from unfinished ranks is arithmetic on garbage, never an address
+        *pending = flag;
+    } else {
+        unsigned over = 0;
+        WN_HIP(ctx, hipMemcpyAsync(&over, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        WN_HIP(ctx, hipStreamSynchronize(st));
+        if (over) return WN_OK;
+    }
     if (D) {
         hipLaunchKernelGGL(kb_delta_home, grid_for((int)std::min<size_t>(n, 1u << 30), B), dim3(BT), 0, st, Y, rank, D, fg, (unsigned)n);
         WN_HIP(ctx, hipGetLastError());
@@ -938,7 +1014,7 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
 int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB,
                unsigned* idxA, unsigned* idxB, unsigned* cnt, double* gpart, double* fg, double* S_e, void* sort_tmp,
                size_t sort_tmp_bytes, int* rank_slice = nullptr, bool counts_ready = false, unsigned* kmax = nullptr,
-               bool kmax_ready = false) {
+               bool kmax_ready = false, const unsigned** pending = nullptr) {
     // rank_slice (with D null): receives the number of examples per slice when the ranks were left in keysB
     // (slice s at keysB + s * slice * n, as 32-bit ranks at home positions) for a consumer that computes
     // the errors itself, 0 when this path did not apply and only the sums were computed.
@@ -948,7 +1024,7 @@ int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, dou
     while (((size_t)1 << lgn) < n) lgn++;
     if (ctx->bucket_rank && !ctx->exact_sort && kmax) {
         bool ok = false;
-        const int rc = gini_buckets(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, fg, S_e, kmax, kmax_ready, &ok);
+        const int rc = gini_buckets(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, fg, S_e, kmax, kmax_ready, &ok, pending);
         if (rc) return rc;
         if (ok) {
             if (rank_slice) *rank_slice = B;   // one slice: example e's ranks at (unsigned*)keysB + e * n
@@ -1023,6 +1099,7 @@ size_t sort_temp_bytes(size_t total) {
 
 struct Plan {
     int Bc;                 // examples per chunk
+    int pgx;                // partial-sum slots per example the buffers are sized for (>= GXMAX)
     size_t n;
     double *Prow, *Y1, *Pcol, *YD, *A, *Bb, *gpart, *fg, *partial, *grad_e, *S_e;
     unsigned *idxA, *idxB, *cnt, *kmax;
@@ -1039,6 +1116,10 @@ int make_plan(wn_context* ctx, int B, size_t n, int NP, int N, Plan* pl) {
     if (Bc < 1) return fail(ctx, WN_ERR_UNSUPPORTED, "example too large for the streamed path");
     pl->Bc = (int)Bc;
     pl->n = n;
+    // partial-sum slots per example.  (More of them for chunks of few examples do not pay: the reducing kernels hold
+    // two workgroups per CU in registers, and every further workgroup only adds its own prologue and reduction.)
+    const int pgx = GXMAX;
+    pl->pgx = pgx;
     pl->sort_tmp_bytes = sort_temp_bytes(Bc * n);
     for (int pass = 0; pass < 2; pass++) {
         Carver c{pass ? (char*)ctx->workspace : nullptr};
@@ -1054,7 +1135,7 @@ int make_plan(wn_context* ctx, int B, size_t n, int NP, int N, Plan* pl) {
         pl->kmax = c.take<unsigned>(Bc + 16);
         pl->gpart = c.take<double>(Bc * GXMAX * 2);
         pl->fg = c.take<double>(Bc * 2);
-        pl->partial = c.take<double>(Bc * GXMAX * 2 * NP);
+        pl->partial = c.take<double>(Bc * (size_t)pgx * 2 * NP);
         pl->grad_e = c.take<double>(Bc * N);
         pl->S_e = c.take<double>(Bc);
         pl->sort_tmp = c.take<char>(pl->sort_tmp_bytes);
@@ -1079,7 +1160,9 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
     if (rc) return rc;
     hipStream_t st = ctx->stream;
     const Geom rg = row_geom(lgR, lgC), cg = col_geom(lgR, lgC);
-    for (int e0 = 0; e0 < B; e0 += pl.Bc) {
+    // One chunk; with *pending set on return, the bucket ranking's verdict (a device flag) is still out.
+    auto run_chunk = [&](int e0, bool try_buckets, const unsigned** pending) -> int {
+        int rc = WN_OK;
         const int Bc = std::min(pl.Bc, B - e0);
         const double* Xc = X + (size_t)e0 * n;
         double* Prow = ProwOut ? ProwOut + (size_t)e0 * n : pl.Prow;
@@ -1098,14 +1181,17 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         const int Mrow = C / 64, Mcol = R / 64;     // samples per lane
         const bool rowLines = (NP <= 8 && lgC >= 7 && lgC <= 10 && R >= line_tile_rows(Mrow) && ctx->wave64 && !ProwOut);
         const bool colLines = ((NP <= 8 || (NP == 16 && (lgR == 8 || lgR == 9))) && lgR >= 7 && lgR <= 10 && lgC > 0 && ctx->wave64);
-        const bool buckets = ctx->bucket_rank && !ctx->exact_sort && (lgR + lgC) <= rk::RK_LGN_MAX;
+        const bool buckets = try_buckets && ctx->bucket_rank && !ctx->exact_sort && (lgR + lgC) <= rk::RK_LGN_MAX;
         const double* Yc = YD;
         double* pcolArg = PcolOut ? Pcol : nullptr;
         size_t xs = n;
         int ncols = C, nrows = R;
         const FilterDev* dfilt = ctx->dfilt;
         double* partial = pl.partial;
-        if (rowLines) {
+        if (lgC == 0 && !Y1Out && !ProwOut) {
+            // 1D: the row pass is the identity, so the column pass reads the signals where they are
+            Y1 = const_cast<double*>(Xc);
+        } else if (rowLines) {
             const void* fwd = line_kernel(NP, LN_FWD_ROWS, Mrow);
             const void* grd = line_kernel(NP, LN_GRAD_ROWS, Mrow);
             // LDS beyond the default limit
@@ -1123,26 +1209,28 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
             unsigned* counts = (forward_only || buckets) ? nullptr : pl.cnt;
             unsigned* kmaxArg = (!forward_only && buckets) ? pl.kmax : nullptr;
             if (counts) WN_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)Bc * (n / CP_BLOCK) * sizeof(unsigned), st));
-            if (kmaxArg) WN_HIP(ctx, hipMemsetAsync(kmaxArg, 0, (size_t)Bc * sizeof(unsigned), st));
+            if (kmaxArg) WN_HIP(ctx, hipMemsetAsync(kmaxArg, 0, (size_t)(Bc + 16) * sizeof(unsigned), st));   // and the ranking's flag behind them
             void* args[] = {(void*)&y1c, (void*)&YD, (void*)&pcolArg, (void*)&xs, (void*)&ncols, (void*)&dfilt, (void*)&counts, (void*)&kmaxArg};
             WN_HIP(ctx, hipLaunchKernel(line_kernel(NP, LN_FWD_COLS, Mcol), dim3(std::min(C, LN_GX), Bc), dim3(64), args, 0, st));
         } else if ((rc = fwd_pass_big<NP>(ctx, Y1, Pcol, YD, Bc, n, cg))) {
             return rc;
         }
-        if (forward_only) continue;
+        if (forward_only) return WN_OK;
         double* S_e = S ? S + e0 : pl.S_e;
         double* grad_e = grad ? grad + (size_t)e0 * N : pl.grad_e;
         // with the column kernels the errors on the coefficients are computed inside the backward kernel from
         // the ranks; otherwise (or when the short-key ranking did not apply) they replace the coefficients in YD
         int rank_slice = 0;
         if (colLines && (rc = gini_large(ctx, YD, nullptr, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp,
-                                         pl.sort_tmp_bytes, &rank_slice, !buckets, pl.kmax, buckets)))
+                                         pl.sort_tmp_bytes, &rank_slice, !buckets, buckets ? pl.kmax : nullptr, buckets, pending)))
             return rc;
         if (!rank_slice &&
             (rc = gini_large(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes,
-                             nullptr, false, pl.kmax, false)))
+                             nullptr, false, try_buckets ? pl.kmax : nullptr, false, pending)))
             return rc;
-        WN_HIP(ctx, hipMemsetAsync(pl.partial, 0, (size_t)Bc * GXMAX * 2 * NP * sizeof(double), st));
+        // the one-wave-per-line kernels write GXMAX slots per example
+        const int pgx = (rowLines || colLines) ? GXMAX : pl.pgx;
+        WN_HIP(ctx, hipMemsetAsync(pl.partial, 0, (size_t)Bc * pgx * 2 * NP * sizeof(double), st));
         const double* D1 = nullptr;
         if (colLines) {
             const double* y1c = Y1;
@@ -1155,7 +1243,7 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
             WN_HIP(ctx, hipLaunchKernel(line_kernel(NP, rank_slice ? LN_BWD_COLS_RANKS : LN_BWD_COLS, Mcol), dim3(std::min(C, LN_GX), Bc),
                                         dim3(64), args, 0, st));
             D1 = pl.A;
-        } else if ((rc = bwd_pass_big<NP>(ctx, YD, Y1, Pcol, pl.A, pl.Bb, Bc, n, cg, lgC > 0, pl.partial, &D1, Yout ? nullptr : YD))) {
+        } else if ((rc = bwd_pass_big<NP>(ctx, YD, Y1, Pcol, pl.A, pl.Bb, Bc, n, cg, lgC > 0, pl.partial, pgx, &D1, Yout ? nullptr : YD))) {
             return rc;
         }
         if (lgC > 0) {
@@ -1165,16 +1253,38 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
                 void* args[] = {(void*)&D1, (void*)&Xc, (void*)&xs, (void*)&nrows, (void*)&dfilt, (void*)&partial};
                 WN_HIP(ctx, hipLaunchKernel(line_kernel(NP, LN_GRAD_ROWS, Mrow), dim3(std::min(R / line_tile_rows(Mrow), LN_GX), Bc),
                                             dim3(256), args, line_tile_bytes(Mrow), st));
-            } else if ((rc = bwd_pass_big<NP>(ctx, D1, Xc, Prow, other, Pcol, Bc, n, rg, false, pl.partial, nullptr))) {
+            } else if ((rc = bwd_pass_big<NP>(ctx, D1, Xc, Prow, other, Pcol, Bc, n, rg, false, pl.partial, pgx, nullptr))) {
                 return rc;
             }
         }
-        hipLaunchKernelGGL(kb_grad_finish, dim3(Bc), dim3(64), 0, st, pl.partial, NP, ctx->dfilt, grad_e);
-        hipLaunchKernelGGL(kb_batch_sums, dim3(N + 2), dim3(64), 0, st, grad_e, S_e, Bc, N, ctx->sums, e0 == 0 ? 1 : 0);
+        hipLaunchKernelGGL(kb_grad_finish, dim3(Bc), dim3(256), 0, st, pl.partial, NP, ctx->dfilt, grad_e, pgx);
+        hipLaunchKernelGGL(kb_batch_sums, dim3(N + 2), dim3(64), 0, st, grad_e, S_e, Bc, N, ctx->sums, e0 == 0 ? 1 : 0, *pending);
         WN_HIP(ctx, hipGetLastError());
+        return WN_OK;
+    };
+    for (int e0 = 0; e0 < B; e0 += pl.Bc) {
+        // The bucket ranking gives up on an example whose magnitudes crowd into one bucket, and says so in a device flag.
+        // Rather than wait for that verdict in the middle of the chunk with the GPU idle, everything is queued first
+        // (kb_batch_sums keeps its hands off the sums when the flag is up) and the chunk is done again without the
+        // bucket ranking in the rare case that it has to be.
+        const unsigned* pending = nullptr;
+        if ((rc = run_chunk(e0, true, &pending))) return rc;
+        if (pending) {
+            unsigned over = 0;
+            WN_HIP(ctx, hipMemcpyAsync(&over, pending, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            WN_HIP(ctx, hipStreamSynchronize(st));
+            if (over) {
+                if (getenv("WAVENET_HIP_VERBOSE"))
+                    fprintf(stderr, "wavenet_hip: bucket ranking gave up on a chunk of %d examples of %zu coefficients, radix sort instead\n",
+                            std::min(pl.Bc, B - e0), n);
+                pending = nullptr;
+                if ((rc = run_chunk(e0, false, &pending))) return rc;
+            }
+        }
     }
     return WN_OK;
 }
+
 
 template <int NP>
 int inverse_impl(wn_context* ctx, const double* Y, int B, int lgR, int lgC, double* Xout) {
@@ -1188,9 +1298,9 @@ int inverse_impl(wn_context* ctx, const double* Y, int B, int lgR, int lgC, doub
         const double* Yc = Y + (size_t)e0 * n;
         const double* mid = nullptr;
         const double* fin = nullptr;
-        if ((rc = bwd_pass_big<NP>(ctx, Yc, nullptr, nullptr, pl.A, pl.Bb, Bc, n, cg, true, nullptr, &mid))) return rc;
+        if ((rc = bwd_pass_big<NP>(ctx, Yc, nullptr, nullptr, pl.A, pl.Bb, Bc, n, cg, true, nullptr, GXMAX, &mid))) return rc;
         double* s1 = (mid == pl.A) ? pl.Bb : pl.A;
-        if ((rc = bwd_pass_big<NP>(ctx, mid, nullptr, nullptr, s1, pl.Pcol, Bc, n, rg, true, nullptr, &fin))) return rc;
+        if ((rc = bwd_pass_big<NP>(ctx, mid, nullptr, nullptr, s1, pl.Pcol, Bc, n, rg, true, nullptr, GXMAX, &fin))) return rc;
         WN_HIP(ctx, hipMemcpyAsync(Xout + (size_t)e0 * n, fin, (size_t)Bc * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     }
     return WN_OK;
@@ -1209,15 +1319,16 @@ int backprop_impl(wn_context* ctx, const double* Delta, const double* X, const d
     for (int e0 = 0; e0 < B; e0 += pl.Bc) {
         const int Bc = std::min(pl.Bc, B - e0);
         const size_t o = (size_t)e0 * n;
-        WN_HIP(ctx, hipMemsetAsync(pl.partial, 0, (size_t)Bc * GXMAX * 2 * NP * sizeof(double), st));
+        const int pgx = pl.pgx;
+        WN_HIP(ctx, hipMemsetAsync(pl.partial, 0, (size_t)Bc * pgx * 2 * NP * sizeof(double), st));
         const double* D1 = nullptr;
-        if ((rc = bwd_pass_big<NP>(ctx, Delta + o, Y1 + o, Pcol + o, pl.A, pl.Bb, Bc, n, cg, true, pl.partial, &D1))) return rc;
+        if ((rc = bwd_pass_big<NP>(ctx, Delta + o, Y1 + o, Pcol + o, pl.A, pl.Bb, Bc, n, cg, true, pl.partial, pgx, &D1))) return rc;
         if (din) WN_HIP(ctx, hipMemcpyAsync(din + o, D1, (size_t)Bc * n * sizeof(double), hipMemcpyDeviceToDevice, st));
         if (lgC > 0) {
             double* other = (D1 == pl.A) ? pl.Bb : pl.A;
-            if ((rc = bwd_pass_big<NP>(ctx, D1, X + o, Prow + o, other, pl.Pcol, Bc, n, rg, false, pl.partial, nullptr))) return rc;
+            if ((rc = bwd_pass_big<NP>(ctx, D1, X + o, Prow + o, other, pl.Pcol, Bc, n, rg, false, pl.partial, pgx, nullptr))) return rc;
         }
-        hipLaunchKernelGGL(kb_grad_finish, dim3(Bc), dim3(64), 0, st, pl.partial, NP, ctx->dfilt, grad + (size_t)e0 * N);
+        hipLaunchKernelGGL(kb_grad_finish, dim3(Bc), dim3(256), 0, st, pl.partial, NP, ctx->dfilt, grad + (size_t)e0 * N, pgx);
         WN_HIP(ctx, hipGetLastError());
     }
     return WN_OK;

@@ -86,14 +86,30 @@ __global__ __launch_bounds__(RK_PT) void kr_max(const double* __restrict__ Y, si
     const size_t per = n / gridDim.x;
     const double* src = Y + (size_t)blockIdx.y * n + (size_t)blockIdx.x * per;
     unsigned m = 0;
-    for (size_t i = 2 * threadIdx.x; i < per; i += 2 * RK_PT) {
-        const double2 v = *reinterpret_cast<const double2*>(src + i);
-        const unsigned k0 = (unsigned)__double2hiint(v.x) & 0x7FFFFFFFu, k1 = (unsigned)__double2hiint(v.y) & 0x7FFFFFFFu;
-        m = max(m, max(k0, k1));
+    for (size_t i0 = 0; i0 < per; i0 += 16 * RK_PT) {
+        double2 v[8];   // eight loads in flight
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const size_t i = i0 + 2 * (size_t)(k * RK_PT + threadIdx.x);
+            v[k] = (i < per) ? *reinterpret_cast<const double2*>(src + i) : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned k0 = (unsigned)__double2hiint(v[k].x) & 0x7FFFFFFFu, k1 = (unsigned)__double2hiint(v[k].y) & 0x7FFFFFFFu;
+            m = max(m, max(k0, k1));
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(&kmax[blockIdx.y], m);
+    // one atomic per workgroup: atomics on one address are served one after the other
+    __shared__ unsigned wmax[RK_PT / 64];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < RK_PT / 64; w++) m = max(m, wmax[w]);
+        if (m) atomicMax(&kmax[blockIdx.y], m);
+    }
 }
 
 // hist[e][f] (+)= number of non-zero coefficients of example e in bin f; grid (G, B), NF * 4 bytes of LDS.
@@ -476,22 +492,28 @@ __global__ __launch_bounds__(RK_KT, 4) void kr_bucket(const unsigned long long* 
     }
 }
 
-// fg[2e] = f, fg[2e+1] = g = n sum |c|, S_e[e] = 1 - f / g: the buckets' shares in bucket order.
-__global__ void kr_finish(unsigned* meta_all, size_t n, int B, double* fg, double* S_e) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+// fg[2e] = f, fg[2e+1] = g = n sum |c|, S_e[e] = 1 - f / g.  One wave per example (grid B, 64 threads): lane l
+// adds the shares of buckets l, l + 64, ... in order, the lanes are combined by a butterfly -- a fixed order.
+__global__ __launch_bounds__(64) void kr_finish(unsigned* meta_all, size_t n, int B, double* fg, double* S_e) {
+    const int e = blockIdx.x, lane = threadIdx.x;
     if (e >= B) return;
     const int nbmax = nbmax_for(n);
     unsigned* meta = meta_all + (size_t)e * meta_words(n);
     const int nb = (int)meta[1];
     const double* bp = meta_bpart(meta, nbmax);
+    const unsigned* bs = meta_bstart(meta);
     double f = 0, a = 0;
-    for (int b = 0; b < nb; b++) {
-        if (meta_bstart(meta)[b + 1] != meta_bstart(meta)[b]) { f += bp[2 * b]; a += bp[2 * b + 1]; }
+    for (int b = lane; b < nb; b += 64) {
+        if (bs[b + 1] != bs[b]) { f += bp[2 * b]; a += bp[2 * b + 1]; }
     }
-    const double g = (double)n * a;
-    fg[2 * e] = f;
-    fg[2 * e + 1] = g;
-    if (S_e) S_e[e] = 1.0 - f / g;
+    f = wave_sum(f);
+    a = wave_sum(a);
+    if (lane == 0) {
+        const double g = (double)n * a;
+        fg[2 * e] = f;
+        fg[2 * e + 1] = g;
+        if (S_e) S_e[e] = 1.0 - f / g;
+    }
 }
 
 }  // namespace rk
