@@ -1,10 +1,11 @@
 #!/bin/bash
 # SQ / TCC counter passes over one bench workload (one counter group per run), on the GPU box:
-#   tools/pmc_workload.sh <workload> <tag>      e.g. tools/pmc_workload.sh 1d1024 r02
+#   tools/pmc_workload.sh <workload> <tag> [groups]     e.g. tools/pmc_workload.sh 1d1024 r02 "fetch write sq1 sq2"
 # The per-dispatch tables land in gpurun_out/pmc/<tag>_<workload>_<group>.csv.
 set -u
 W=$1
 TAG=$2
+GROUPS_WANTED=${3:-"fetch write sq1 sq2"}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/pmc
 mkdir -p $OUT
@@ -16,6 +17,11 @@ run() {
   cp $(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1) $OUT/${TAG}_${W}_$name.csv
   echo "pass $name done"
 }
-run fetch FETCH_SIZE && run write WRITE_SIZE \
-  && run sq1 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAVES SQ_INSTS_SMEM \
-  && run sq2 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM
+for grp in $GROUPS_WANTED; do
+  case $grp in
+    fetch) run fetch FETCH_SIZE || exit 1 ;;
+    write) run write WRITE_SIZE || exit 1 ;;
+    sq1) run sq1 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAVES SQ_INSTS_SMEM || exit 1 ;;
+    sq2) run sq2 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM || exit 1 ;;
+  esac
+done
