@@ -9,7 +9,7 @@ B, n = 4096, 1024
 ctx = Context(0, stream=torch.cuda.current_stream().cuda_stream)
 rng = np.random.default_rng(0)
 inputs = {"normal": rng.standard_normal((B, n, 1)), "bumps": G.bumps(B, n, seed=1000).reshape(B, n, 1), "uniform": rng.random((B, n, 1))}
-for N in (4, 8, 16, 32):
+for N in (int(v) for v in (sys.argv[1:] or ["4", "8", "16", "32"])):
     ctx.set_filter(perturbed(daubechies(N), 1e-2, seed=7))
     for name, X in inputs.items():
         dX = torch.from_numpy(to_device_layout(X)).cuda()

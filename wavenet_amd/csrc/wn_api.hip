@@ -634,7 +634,7 @@ static int train_fused(wn_context* ctx, const double* X, int B, int lgR, int lgC
             rc = launch(ctx, wn_kernel_wave1d_line(ctx->NP, 1 << (lgR - 6)), 64, std::max<size_t>((512 + 8) * sizeof(double), wn::TAIL_LDS_BYTES), B, A, &grid, max_slots);
         } else if (lgR == 10 && lgC == 0 && ctx->wave64) {
             // 1D signals of 1024 samples: one wave per example, one example in flight per workgroup
-            rc = launch(ctx, wn_kernel_wave1d(ctx->NP), 64, (size_t)(1024 + 64 + 256 + 8) * sizeof(double), B, A, &grid, max_slots);
+            rc = launch(ctx, wn_kernel_wave1d(ctx->NP), 64, (size_t)(1024 + 64 + 256 + 8 + (ctx->NP == 16 ? 15 * 64 : 0)) * sizeof(double), B, A, &grid, max_slots);
         } else {
             // X, row-stage coefficients (2D only), pyramid, coefficients / sort slots, reduction scratch
             const size_t shmem = std::max<size_t>(((size_t)(lgC > 0 ? 3 : 2) * R * C + S.NS + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double) + 16,
