@@ -136,6 +136,48 @@ def test_train_batch(ctx, oracle, R, C, N, B):
     assert np.array_equal(ctx.sums(), sums)
 
 
+@pytest.mark.parametrize("R,C,N", [(16384, 1, 2), (256, 128, 2)])
+def test_train_batch_when_the_bucket_ranking_gives_up(oracle, capfd, monkeypatch, R, C, N):
+    """An example whose coefficients crowd into one bucket (a constant signal with alternating sign under the
+    two-tap averaging filter: thousands of coefficients of one magnitude) makes the bucket ranking give up on its chunk.  The
+    training step has queued the whole chunk by the time the host sees that, and computes it again with the radix
+    ranking; the sums must be those of the oracle, with no trace of the abandoned attempt -- also when the chunk
+    is not the first one of the batch."""
+    import torch
+    from wavenet_amd import generators as G
+    monkeypatch.setenv("WAVENET_HIP_VERBOSE", "1")
+    B = 5
+    # taps that are powers of two: every product and sum of the crowded example is exact, so its thousands of equal
+    # magnitudes are equal bit for bit here and in the oracle, and both order them by index (with rounding in play the
+    # two would break the near-ties differently, and the Gini gradient is discontinuous there)
+    a = np.array([0.5, 0.5])
+    X = G.calorimeter(B, R, C, seed=5) if C > 1 else G.bumps(B, R, seed=5).reshape(B, R, C)
+    sign = np.where((np.arange(R)[:, None] + np.arange(C)[None, :]) % 2 == 0, 1.0, -1.0)
+    X[3] = 0.75 * sign
+    c = _ctx_with_env("WAVENET_HIP_CHUNK", "2")      # chunks of two examples: the crowded one sits in the second chunk
+    try:
+        c.set_filter(a)
+        dG, dS = dev_empty(B * N), dev_empty(B)
+        c.train_batch(to_dev(X), B, R, C, dG, dS)
+        torch.cuda.synchronize()
+        sums = c.sums()
+        err = capfd.readouterr().err
+        assert "bucket ranking gave up" in err
+        og, os_, bad = oracle.band_train_batch(a, X)
+        assert bad == 0 and sums[N + 1] == 0
+        assert relerr(sums[:N], og) < 1e-9
+        assert sums[N] == pytest.approx(os_, rel=1e-11)
+        Sd = dS.cpu().numpy()
+        for e in range(B):
+            assert Sd[e] == pytest.approx(oracle.band_train_batch(a, X[e:e + 1])[1], rel=1e-11)
+        # the same batch again gives the same sums (nothing of the abandoned attempt is left behind)
+        c.train_batch(to_dev(X), B, R, C)
+        assert np.array_equal(c.sums(), sums)
+    finally:
+        torch.cuda.synchronize()
+        c.close()
+
+
 def test_full_size_properties_512(ctx):
     """Size-independent properties at 512x512: perfect reconstruction for an orthonormal filter, linearity of
     the forward transform, and energy conservation (Parseval) of the coefficients."""

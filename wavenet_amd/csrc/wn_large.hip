@@ -1113,6 +1113,7 @@ int make_plan(wn_context* ctx, int B, size_t n, int NP, int N, Plan* pl) {
     size_t Bc = std::max<size_t>(1, std::min<size_t>((size_t)B, cap / per_example));
     Bc = std::min<size_t>(Bc, ((size_t)1 << 31) / n);  // chunk positions are kept in 32 bits
     Bc = std::min<size_t>(Bc, 65535);                   // grid.y
+    if (ctx->chunk_cap > 0) Bc = std::min<size_t>(Bc, (size_t)ctx->chunk_cap);
     if (Bc < 1) return fail(ctx, WN_ERR_UNSUPPORTED, "example too large for the streamed path");
     pl->Bc = (int)Bc;
     pl->n = n;
