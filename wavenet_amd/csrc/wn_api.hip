@@ -157,11 +157,33 @@ __global__ __launch_bounds__(64) void k_update(wn::FilterDev* f, const double* s
 // caller's all-reduce (mode 1).
 __global__ __launch_bounds__(1024) void k_finish(const double* partial, int nslots, wn::StepTail S) {
     __shared__ double ssum[wn::PSTRIDE];
+    __shared__ double lsum[wn::PSTRIDE][64];
     __shared__ wn::UpdateShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = S.filt->N;
-    for (int q = wave; q <= N + 1; q += 16) {
-        const double s = wn::reduce_slots(partial, nslots, wn::PSTRIDE, q, lane);
+    const int N = S.filt->N, nq = N + 2;
+    // The sums in the order of reduce_slots (slots l, l + 64, ... added up in order, then the 64 partial results by
+    // a shuffle tree), computed from whole rows: a thread owns (l, quantity) pairs with consecutive threads on
+    // consecutive quantities of a slot, so the slots are read as rows, not as one cache line per lane and quantity.
+    for (int pair = tid; pair < 64 * nq; pair += 1024) {
+        const int l = pair / nq, q = pair - l * nq;
+        double s = 0;
+        for (int base = l; base < nslots; base += 64 * 16) {
+            double v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int slot = base + 64 * i;
+                v[i] = (slot < nslots) ? partial[(size_t)slot * wn::PSTRIDE + q] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (base + 64 * i < nslots) s += v[i];
+            }
+        }
+        lsum[q][l] = s;
+    }
+    __syncthreads();
+    for (int q = wave; q < nq; q += 16) {
+        const double s = wn::wave_sum(lsum[q][lane]);
         if (lane == 0) { ssum[q] = s; S.sums[q] = s; }
     }
     __syncthreads();
