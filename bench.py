@@ -6,7 +6,7 @@ reduction + filter update) on MI355X, one process per GPU.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step is one pass of the hot path over one batch resident in HBM.  Rank 0 prints one JSON line per
-workload; the LAST line is the headline, the configuration BASELINE.json's metric is quoted on: 2D 64x64
+workload; the LAST line is the headline, the configuration the headline metric is quoted on: 2D 64x64
 calorimeter-style images, batch 4096 per GPU, 4-tap filter.  On one GPU the default run first prints a
 line each for the other configurations (64x64 with 16 taps, 1D 1024 / 16 taps, the per-GPU slices of
 512x512 / batch 16384 over 8 GPUs and of 2^20-sample signals / 32 taps); with more ranks only the headline
