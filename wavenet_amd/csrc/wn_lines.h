@@ -156,6 +156,14 @@ struct LineGini {
 
 #define LN_BOUNDS(T) __launch_bounds__(T, (NP > 16 ? 1 : 2))
 
+// The thread index as a value the compiler cannot see through.  Taken at the top of every pass of a kernel's loop
+// over lines or tiles: the addresses derived from it are then computed where they are used instead of being
+// hoisted out of the loop and held in registers (or scratch memory) all the way through.
+__device__ __forceinline__ int ln_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // ---- columns: contiguous lines of 64 M samples ---------------------------------------------------------
 // grid (workgroups per example, examples), 64 threads.  in/Y/P: chunk arrays, example stride xs, column c
 // of an example at c * 64 M.  P may be null.  counts (may be null): counts[i] receives (is added) the number
@@ -165,12 +173,13 @@ struct LineGini {
 template <int NP, int M>
 __global__ LN_BOUNDS(64) void kc_fwd_cols(const double* __restrict__ in, double* __restrict__ Y, double* __restrict__ P, size_t xs,
                                           int ncols, const FilterDev* filt, unsigned* counts, unsigned* kmax) {
-    const int lane = threadIdx.x;
+    const int lane0 = threadIdx.x;
     double a[NP], b[NP];
     ln_load_taps<NP>(filt, a, b);
     const size_t off = (size_t)blockIdx.y * xs;
     unsigned kmine = 0;
     for (int c = blockIdx.x; c < ncols; c += gridDim.x) {
+        const int lane = ln_opaque(lane0);
         const size_t lo = off + (size_t)c * (64 * M);
         LinePyramid<M> p;
         LineLane<M> y;
@@ -193,7 +202,7 @@ __global__ LN_BOUNDS(64) void kc_fwd_cols(const double* __restrict__ in, double*
     if (kmax) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) kmine = max(kmine, (unsigned)__shfl_xor((int)kmine, o, 64));
-        if (lane == 0 && kmine) atomicMax(&kmax[blockIdx.y], kmine);
+        if (lane0 == 0 && kmine) atomicMax(&kmax[blockIdx.y], kmine);
     }
 }
 
@@ -208,7 +217,7 @@ template <int NP, int M, bool FROM_RANKS>
 __global__ LN_BOUNDS(64) void kc_bwd_cols(const double* __restrict__ coef, const double* __restrict__ in, double* __restrict__ out,
                                           size_t xs, int ncols, const FilterDev* filt, double* partial, const double* ranks,
                                           int slice, const double* fg) {
-    const int lane = threadIdx.x;
+    const int lane0 = threadIdx.x;
     double a[NP], b[NP];
     ln_load_taps<NP>(filt, a, b);
     double gL[NP], gH[NP];
@@ -225,6 +234,7 @@ __global__ LN_BOUNDS(64) void kc_bwd_cols(const double* __restrict__ coef, const
         gini.inv_g2 = 1.0 / (gini.g * gini.g);
     }
     for (int c = blockIdx.x; c < ncols; c += gridDim.x) {
+        const int lane = ln_opaque(lane0);
         const size_t lo = off + (size_t)c * (64 * M);
         LinePyramid<M> p;
         LineLane<M> unused_y, dy;
@@ -256,7 +266,7 @@ __global__ LN_BOUNDS(64) void kc_bwd_cols(const double* __restrict__ coef, const
         double sl = gL[u], sh = gH[u];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { sl += __shfl_xor(sl, o, 64); sh += __shfl_xor(sh, o, 64); }
-        if (lane == 0) { part[u] += sl; part[NP + u] += sh; }
+        if (lane0 == 0) { part[u] += sl; part[NP + u] += sh; }
     }
 }
 
@@ -275,12 +285,12 @@ struct LineTile {
 
 // ROWS adjacent rows of one example between memory (element (r, c) at r + R c) and the tile; 256 threads
 template <int M, bool TO_TILE>
-__device__ __forceinline__ void ln_move_tile(double* tile, double* mem, int R) {
+__device__ __forceinline__ void ln_move_tile(double* tile, double* mem, int R, int tid) {
     using T = LineTile<M>;
-    const int rp = threadIdx.x % T::PAIRS;
+    const int rp = tid % T::PAIRS;
 #pragma unroll 4
     for (int it = 0; it < T::STEPS; it++) {
-        const int c = threadIdx.x / T::PAIRS + T::COLS_PER_STEP * it;
+        const int c = tid / T::PAIRS + T::COLS_PER_STEP * it;
         double2* g = reinterpret_cast<double2*>(mem + 2 * rp + (size_t)R * c);
         double* t = tile + (2 * rp) * T::RS + T::pad(c);
         if constexpr (TO_TILE) {
@@ -323,13 +333,13 @@ __global__ LN_BOUNDS(256) void kr_fwd_rows(const double* __restrict__ in, double
                                            const FilterDev* filt) {
     using T = LineTile<M>;
     extern __shared__ __attribute__((aligned(16))) double ln_tile[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double a[NP], b[NP];
     ln_load_taps<NP>(filt, a, b);
     for (int tile = blockIdx.x; tile < R / T::ROWS; tile += gridDim.x) {
+        const int tid = ln_opaque((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
         const size_t base = (size_t)blockIdx.y * xs + (size_t)tile * T::ROWS;
         __syncthreads();
-        ln_move_tile<M, true>(ln_tile, const_cast<double*>(in) + base, R);
+        ln_move_tile<M, true>(ln_tile, const_cast<double*>(in) + base, R, tid);
         __syncthreads();
         for (int j = wave; j < T::ROWS; j += 4) {
             double* row = ln_tile + j * T::RS;
@@ -341,7 +351,7 @@ __global__ LN_BOUNDS(256) void kr_fwd_rows(const double* __restrict__ in, double
             ln_row_store<M>(row, y, lane);      // in place: the row is in this wave's registers
         }
         __syncthreads();
-        ln_move_tile<M, false>(ln_tile, Y + base, R);
+        ln_move_tile<M, false>(ln_tile, Y + base, R, tid);
     }
 }
 
@@ -353,22 +363,22 @@ __global__ LN_BOUNDS(256) void kr_grad_rows(const double* __restrict__ coef, con
     using T = LineTile<M>;
     constexpr int PER_WAVE = T::ROWS / 4;
     extern __shared__ __attribute__((aligned(16))) double ln_tile[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double a[NP], b[NP];
     ln_load_taps<NP>(filt, a, b);
     double gL[NP], gH[NP];
 #pragma unroll
     for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
     for (int tile = blockIdx.x; tile < R / T::ROWS; tile += gridDim.x) {
+        const int tid = ln_opaque((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
         const size_t base = (size_t)blockIdx.y * xs + (size_t)tile * T::ROWS;
         double xr[PER_WAVE][M];
         __syncthreads();
-        ln_move_tile<M, true>(ln_tile, const_cast<double*>(in) + base, R);
+        ln_move_tile<M, true>(ln_tile, const_cast<double*>(in) + base, R, tid);
         __syncthreads();
 #pragma unroll
         for (int jj = 0; jj < PER_WAVE; jj++) ln_row_samples<M>(ln_tile + (wave + 4 * jj) * T::RS, xr[jj], lane);
         __syncthreads();
-        ln_move_tile<M, true>(ln_tile, const_cast<double*>(coef) + base, R);
+        ln_move_tile<M, true>(ln_tile, const_cast<double*>(coef) + base, R, tid);
         __syncthreads();
 #pragma unroll
         for (int jj = 0; jj < PER_WAVE; jj++) {
@@ -383,6 +393,7 @@ __global__ LN_BOUNDS(256) void kr_grad_rows(const double* __restrict__ coef, con
         }
     }
     __syncthreads();                        // the tile is free: sums of the four waves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* red = ln_tile;
 #pragma unroll
     for (int u = 0; u < NP; u++) {
