@@ -698,7 +698,14 @@ int wn_train_batch(wn_context* ctx, const double* X, int B, int R, int C, double
         }
         return WN_OK;
     }
-    return train_fused(ctx, X, B, lgR, lgC, sc, grad, Sout, ctx->partial, ctx->partial_blocks, ctx->sums);
+    // the sums are added up where wn_train_step adds them (mode 1: no update) -- for 64x64 images inside the training
+    // kernel, which saves the data-parallel loop (this call, all-reduce, wn_apply_update) a launch per batch
+    wn::StepTail T{};
+    T.ticket = ctx->ticket;
+    T.sums = ctx->sums;
+    T.filt = ctx->dfilt;
+    T.mode = 1;
+    return train_fused(ctx, X, B, lgR, lgC, sc, grad, Sout, ctx->partial, ctx->partial_blocks, ctx->sums, B > 0 ? &T : nullptr);
 }
 
 int wn_train_batch_static(wn_context* ctx, const double* X, int B, int R, int C, double* sums_dev) {
