@@ -295,6 +295,7 @@ int wn_create(int device, wn_context** out) {
 }
 
 int wn_destroy(wn_context* ctx) {
+    wn::make_current(ctx);
     if (!ctx) return WN_OK;
     (void)hipSetDevice(ctx->device);
     wn_comm_destroy(ctx);
@@ -317,6 +318,7 @@ int wn_destroy(wn_context* ctx) {
 }
 
 int wn_set_stream(wn_context* ctx, void* hip_stream) {
+    wn::make_current(ctx);
     if (!ctx) return WN_ERR_ARG;
     WN_HIP(ctx, hipSetDevice(ctx->device));
     WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -327,12 +329,14 @@ int wn_set_stream(wn_context* ctx, void* hip_stream) {
 }
 
 int wn_synchronize(wn_context* ctx) {
+    wn::make_current(ctx);
     if (!ctx) return WN_ERR_ARG;
     WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return WN_OK;
 }
 
 int wn_malloc(wn_context* ctx, void** dev_ptr, size_t bytes) {
+    wn::make_current(ctx);
     if (!ctx || !dev_ptr) return WN_ERR_ARG;
     WN_HIP(ctx, hipSetDevice(ctx->device));
     WN_HIP(ctx, hipMalloc(dev_ptr, bytes ? bytes : 8));
@@ -340,6 +344,7 @@ int wn_malloc(wn_context* ctx, void** dev_ptr, size_t bytes) {
 }
 
 int wn_free(wn_context* ctx, void* dev_ptr) {
+    wn::make_current(ctx);
     if (!ctx) return WN_ERR_ARG;
     WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     WN_HIP(ctx, hipFree(dev_ptr));
@@ -347,6 +352,7 @@ int wn_free(wn_context* ctx, void* dev_ptr) {
 }
 
 int wn_memcpy_h2d(wn_context* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    wn::make_current(ctx);
     if (!ctx || (bytes && (!dst_dev || !src_host))) return WN_ERR_ARG;
     WN_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -354,6 +360,7 @@ int wn_memcpy_h2d(wn_context* ctx, void* dst_dev, const void* src_host, size_t b
 }
 
 int wn_memcpy_d2h(wn_context* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    wn::make_current(ctx);
     if (!ctx || (bytes && (!dst_host || !src_dev))) return WN_ERR_ARG;
     WN_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -363,6 +370,7 @@ int wn_memcpy_d2h(wn_context* ctx, void* dst_host, const void* src_dev, size_t b
 // ---- filter ---------------------------------------------------------------------------------------
 
 int wn_set_filter(wn_context* ctx, const double* a, int N) {
+    wn::make_current(ctx);
     if (!ctx) return WN_ERR_ARG;
     if (!a || N <= 0) return fail(ctx, WN_ERR_BAD_FILTER, "Input filter is empty.");
     if (N % 2) return fail(ctx, WN_ERR_BAD_FILTER, "Input filter length is not a multiple of 2.");
@@ -397,6 +405,7 @@ int wn_set_filter(wn_context* ctx, const double* a, int N) {
 }
 
 int wn_get_filter(wn_context* ctx, double* a, int* N) {
+    wn::make_current(ctx);
     if (!ctx) return WN_ERR_ARG;
     if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
     if (N) *N = ctx->N;
@@ -405,12 +414,14 @@ int wn_get_filter(wn_context* ctx, double* a, int* N) {
 }
 
 int wn_set_momentum(wn_context* ctx, const double* p, int N) {
+    wn::make_current(ctx);
     if (!ctx || !p) return WN_ERR_ARG;
     if (!ctx->has_filter || N != ctx->N) return fail(ctx, WN_ERR_STATE, "momentum length differs from the filter's");
     return wn_memcpy_h2d(ctx, ctx->dfilt->momentum, p, (size_t)N * sizeof(double));
 }
 
 int wn_get_momentum(wn_context* ctx, double* p, int* N) {
+    wn::make_current(ctx);
     if (!ctx) return WN_ERR_ARG;
     if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
     if (N) *N = ctx->N;
@@ -446,6 +457,7 @@ int wn_highpass_operator(const double* a, int N, unsigned size, double* M) {
 // ---- transforms -----------------------------------------------------------------------------------
 
 int wn_forward(wn_context* ctx, const double* X, int B, int R, int C, double* Y, double* Prow, double* Y1, double* Pcol) {
+    wn::make_current(ctx);
     int lgR, lgC, sc;
     int rc = check_shape(ctx, B, R, C, true, &lgR, &lgC, &sc);
     if (rc) return rc;
@@ -464,6 +476,7 @@ int wn_forward(wn_context* ctx, const double* X, int B, int R, int C, double* Y,
 }
 
 int wn_inverse(wn_context* ctx, const double* Y, int B, int R, int C, double* X) {
+    wn::make_current(ctx);
     int lgR, lgC, sc;
     int rc = check_shape(ctx, B, R, C, true, &lgR, &lgC, &sc);
     if (rc) return rc;
@@ -483,6 +496,7 @@ int wn_inverse(wn_context* ctx, const double* Y, int B, int R, int C, double* X)
 
 int wn_backprop(wn_context* ctx, const double* Delta, const double* X, const double* Prow, const double* Y1,
                 const double* Pcol, int B, int R, int C, double* grad, double* din) {
+    wn::make_current(ctx);
     int lgR, lgC, sc;
     int rc = check_shape(ctx, B, R, C, true, &lgR, &lgC, &sc);
     if (rc) return rc;
@@ -503,6 +517,7 @@ int wn_backprop(wn_context* ctx, const double* Delta, const double* X, const dou
 // ---- cost functions -------------------------------------------------------------------------------
 
 int wn_sparse_term_deriv(wn_context* ctx, const double* Y, int B, int n, double* Delta, double* Sout) {
+    wn::make_current(ctx);
     if (!ctx) return WN_ERR_ARG;
     if (B < 0 || n < 1) return fail(ctx, WN_ERR_ARG, "bad counts");
     // any n is accepted by the reference; the sort kernels take powers of two
@@ -524,6 +539,7 @@ int wn_sparse_term_deriv(wn_context* ctx, const double* Y, int B, int n, double*
 }
 
 int wn_sparse_term(wn_context* ctx, const double* Y, int B, int n, double* Sout) {
+    wn::make_current(ctx);
     if (ctx && !Sout) return fail(ctx, WN_ERR_ARG, "null output");
     return wn_sparse_term_deriv(ctx, Y, B, n, nullptr, Sout);
 }
@@ -548,6 +564,7 @@ int wn_reg_term_deriv(const double* a, int N, int do_wavelet, double* grad) {
 
 int wn_sparse_cost_grid(wn_context* ctx, const double* X, int B, int R, int C, const double* filters, int F, int N,
                         double* S) {
+    wn::make_current(ctx);
     int lgR, lgC, sc;
     int rc = check_shape(ctx, B, R, C, false, &lgR, &lgC, &sc);
     if (rc) return rc;
@@ -682,6 +699,7 @@ static int train_fused(wn_context* ctx, const double* X, int B, int lgR, int lgC
 }
 
 int wn_train_batch(wn_context* ctx, const double* X, int B, int R, int C, double* grad, double* Sout) {
+    wn::make_current(ctx);
     int lgR, lgC, sc;
     int rc = check_shape(ctx, B, R, C, true, &lgR, &lgC, &sc);
     if (rc) return rc;
@@ -709,6 +727,7 @@ int wn_train_batch(wn_context* ctx, const double* X, int B, int R, int C, double
 }
 
 int wn_train_batch_static(wn_context* ctx, const double* X, int B, int R, int C, double* sums_dev) {
+    wn::make_current(ctx);
     int lgR, lgC, sc;
     int rc = check_shape(ctx, B, R, C, true, &lgR, &lgC, &sc);
     if (rc) return rc;
@@ -724,6 +743,7 @@ int wn_train_batch_static(wn_context* ctx, const double* X, int B, int R, int C,
 }
 
 int wn_sums(wn_context* ctx, double** sums_dev, int* count) {
+    wn::make_current(ctx);
     if (!ctx) return WN_ERR_ARG;
     if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
     if (sums_dev) *sums_dev = ctx->sums;
@@ -732,6 +752,7 @@ int wn_sums(wn_context* ctx, double** sums_dev, int* count) {
 }
 
 int wn_set_sums_buffer(wn_context* ctx, double* sums_dev) {
+    wn::make_current(ctx);
     if (!ctx) return WN_ERR_ARG;
     WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->sums = sums_dev ? sums_dev : ctx->own_sums;
@@ -739,6 +760,7 @@ int wn_set_sums_buffer(wn_context* ctx, double* sums_dev) {
 }
 
 int wn_profile_begin(wn_context* ctx, int max_records) {
+    wn::make_current(ctx);
     if (!ctx || max_records < 0) return WN_ERR_ARG;
     WN_HIP(ctx, hipSetDevice(ctx->device));
     while ((int)ctx->prof_begin.size() < max_records) {
@@ -759,6 +781,7 @@ int wn_profile_begin(wn_context* ctx, int max_records) {
 }
 
 int wn_profile_collect(wn_context* ctx, float* ms_host, int capacity, int* count) {
+    wn::make_current(ctx);
     if (!ctx || !count || capacity < 0) return WN_ERR_ARG;
     WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int n = ctx->prof_used < capacity ? ctx->prof_used : capacity;
@@ -773,6 +796,7 @@ int wn_profile_collect(wn_context* ctx, float* ms_host, int capacity, int* count
 }
 
 int wn_get_sums(wn_context* ctx, double* sums_host, int* count) {
+    wn::make_current(ctx);
     if (!ctx) return WN_ERR_ARG;
     if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
     if (count) *count = ctx->N + 2;
@@ -797,6 +821,7 @@ static int update_params(wn_context* ctx, double batch_total, double lambda_sum,
 
 int wn_apply_update(wn_context* ctx, double batch_total, double lambda_sum, double alpha, double inertia_eff,
                     int do_wavelet) {
+    wn::make_current(ctx);
     if (!ctx) return WN_ERR_ARG;
     wn::UpdateParams P;
     const int rc = update_params(ctx, batch_total, lambda_sum, alpha, inertia_eff, do_wavelet, &P);
@@ -808,6 +833,7 @@ int wn_apply_update(wn_context* ctx, double batch_total, double lambda_sum, doub
 
 int wn_train_step(wn_context* ctx, const double* X, int B, int R, int C, double batch_total, double lambda_sum,
                   double alpha, double inertia_eff, int do_wavelet) {
+    wn::make_current(ctx);
     int lgR, lgC, sc;
     int rc = check_shape(ctx, B, R, C, true, &lgR, &lgC, &sc);
     if (rc) return rc;
@@ -848,6 +874,7 @@ static int read_update_state(wn_context* ctx, int* steps, int* nonfinite) {
 }
 
 int wn_num_updates(wn_context* ctx, int* steps) {
+    wn::make_current(ctx);
     if (!ctx || !steps) return WN_ERR_ARG;
     int bad = 0;
     const int rc = read_update_state(ctx, steps, &bad);
@@ -859,6 +886,7 @@ int wn_num_updates(wn_context* ctx, int* steps) {
 }
 
 int wn_get_logs(wn_context* ctx, int first, int count, double* filters, double* costs) {
+    wn::make_current(ctx);
     if (!ctx || first < 0 || count < 0) return WN_ERR_ARG;
     if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
     int steps = 0, bad = 0;
@@ -885,6 +913,7 @@ int wn_get_logs(wn_context* ctx, int first, int count, double* filters, double* 
 }
 
 int wn_clear_logs(wn_context* ctx) {
+    wn::make_current(ctx);
     if (!ctx) return WN_ERR_ARG;
     hipLaunchKernelGGL(k_reset_steps, dim3(1), dim3(64), 0, ctx->stream, ctx->dfilt);
     WN_HIP(ctx, hipGetLastError());
@@ -907,6 +936,7 @@ int wn_comm_unique_id(void* id128) {
 }
 
 int wn_comm_init(wn_context* ctx, const void* id128, int nranks, int rank) {
+    wn::make_current(ctx);
     if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return WN_ERR_ARG;
     if (ctx->comm) return fail(ctx, WN_ERR_STATE, "communicator already initialised");
     void* lib = open_rccl();
@@ -980,6 +1010,7 @@ int wn_allreduce_sums_all(wn_context** ctxs, int n) {
 }
 
 int wn_comm_destroy(wn_context* ctx) {
+    wn::make_current(ctx);
     if (!ctx) return WN_ERR_ARG;
     if (ctx->comm && ctx->nccl_lib) {
         auto f = (fn_ncclCommDestroy)dlsym(ctx->nccl_lib, "ncclCommDestroy");
@@ -991,6 +1022,7 @@ int wn_comm_destroy(wn_context* ctx) {
 }
 
 int wn_allreduce_sums(wn_context* ctx) {
+    wn::make_current(ctx);
     if (!ctx) return WN_ERR_ARG;
     if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
     if (!ctx->comm) return fail(ctx, WN_ERR_STATE, "no communicator: call wn_comm_init first");

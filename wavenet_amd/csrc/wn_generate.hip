@@ -121,6 +121,7 @@ int check(wn_context* ctx, int B, int R, int C, const double* X, int* lgR) {
 extern "C" {
 
 int wn_generate_uniform(wn_context* ctx, unsigned long long seed, long long first, int B, int R, int C, double* X) {
+    wn::make_current(ctx);
     int lgR;
     const int rc = check(ctx, B, R, C, X, &lgR);
     if (rc || B == 0) return rc;
@@ -133,6 +134,7 @@ int wn_generate_uniform(wn_context* ctx, unsigned long long seed, long long firs
 
 int wn_generate_needle(wn_context* ctx, unsigned long long seed, long long first, int B, int R, int C, double threshold,
                        double* X) {
+    wn::make_current(ctx);
     int lgR;
     const int rc = check(ctx, B, R, C, X, &lgR);
     if (rc || B == 0) return rc;
@@ -143,6 +145,7 @@ int wn_generate_needle(wn_context* ctx, unsigned long long seed, long long first
 
 int wn_generate_calorimeter(wn_context* ctx, unsigned long long seed, long long first, int B, int R, int C,
                             const int* poisson_table, const double* energy_table, int jets, int jet_deposits, double* X) {
+    wn::make_current(ctx);
     int lgR;
     const int rc = check(ctx, B, R, C, X, &lgR);
     if (rc || B == 0) return rc;

@@ -28,6 +28,7 @@ struct wn_context {
     double* grid_scratch = nullptr;           // coefficients of one batch (shapes without a fused cost kernel)
     size_t grid_scratch_count = 0;
     bool bucket_rank = true;  // streamed path: ranks by histogram + per-bucket LDS sort (WAVENET_HIP_RANK=radix: device-wide radix sort)
+    bool rank_configured = false;   // the ranking kernels' LDS limits have been raised on this context's device
     int chunk_cap = 0;        // streamed path: examples per chunk at most (WAVENET_HIP_CHUNK; 0: as many as the workspace limit allows)
     bool exact_sort = false;  // streamed path: always the 64-bit sort (WAVENET_HIP_EXACT_SORT=1; for tests)
     bool wave64 = true;  // 64x64 training on the one-wave-per-example kernel (WAVENET_HIP_WAVE64=0 turns it off)
@@ -50,6 +51,12 @@ struct wn_context {
 };
 
 namespace wn {
+
+// Every entry point that takes a context starts with this: one host thread may drive contexts on several GPUs (the
+// host layer's data-parallel Coach does), and allocations, attribute changes and launches go to the current device.
+inline void make_current(wn_context* ctx) {
+    if (ctx) (void)hipSetDevice(ctx->device);
+}
 
 inline std::string& global_error() {
     static thread_local std::string e;  // for the entry points that take no context

@@ -967,13 +967,13 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
     unsigned* meta = rank + (size_t)B * n;                                            // B * meta_words(n) words
     unsigned* flag = kmax + B + 4;   // beside the B words of kmax (the plan leaves 16 spare): nothing later in the chunk writes there
     unsigned long long* mag = reinterpret_cast<unsigned long long*>(keysA);
-    static bool configured = false;
-    if (!configured) {
+    // per context, i.e. per device: a function's attributes belong to the device it is loaded on
+    if (!ctx->rank_configured) {
         WN_HIP(ctx, hipFuncSetAttribute((const void*)kr_hist, hipFuncAttributeMaxDynamicSharedMemorySize, RK_NFMAX * 4));
         WN_HIP(ctx, hipFuncSetAttribute((const void*)kr_scan, hipFuncAttributeMaxDynamicSharedMemorySize, RK_NFMAX * 4));
         WN_HIP(ctx, hipFuncSetAttribute((const void*)kr_part<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RK_NFMAX * 2));
         WN_HIP(ctx, hipFuncSetAttribute((const void*)kr_part<false>, hipFuncAttributeMaxDynamicSharedMemorySize, RK_NFMAX * 2));
-        configured = true;
+        ctx->rank_configured = true;
     }
     // workgroups per example: enough of them to fill the chip when the chunk has few examples
     int G = 1;
