@@ -304,6 +304,8 @@ int wn_destroy(wn_context* ctx) {
     (void)hipFree(ctx->partial);
     (void)hipFree(ctx->own_sums);
     (void)hipFree(ctx->ticket);
+    if (ctx->rank_event) (void)hipEventDestroy(ctx->rank_event);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     (void)hipFree(ctx->workspace);
     if (ctx->gen_tables) (void)hipFree(ctx->gen_tables);
     if (ctx->grid_filters) (void)hipFree(ctx->grid_filters);

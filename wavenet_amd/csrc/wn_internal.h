@@ -34,6 +34,10 @@ struct wn_context {
     bool wave64 = true;  // 64x64 training on the one-wave-per-example kernel (WAVENET_HIP_WAVE64=0 turns it off)
     double* sums = nullptr;
     double* own_sums = nullptr;
+    // streamed path: the ranking's give-up flag is fetched on a stream of its own as soon as the ranking kernels are done
+    // (an event on the main stream), while the main stream goes on with the backward pass
+    hipStream_t side_stream = nullptr;
+    hipEvent_t rank_event = nullptr;
     unsigned* ticket = nullptr;  // counter of finished workgroups of a training kernel whose last workgroup ends the step
     std::vector<hipEvent_t> prof_begin, prof_end;
     int prof_used = 0;

@@ -255,6 +255,79 @@ __global__ __launch_bounds__(LT) void kb_fwd_level_lds(const double* __restrict_
     hi[off + k0 + threadIdx.x] = sh;
 }
 
+// NLEV consecutive levels of kb_fwd_level_lds in one launch: a workgroup produces LT outputs of the lowest of them and
+// what that takes of the levels above -- 2 LT + NP - 1 low-pass values of the level before, and so on up to
+// 2^NLEV LT + (2^NLEV - 1)(NP - 1) inputs -- with the intermediate low-pass values handed down through LDS instead of
+// through memory.  The halos are computed again by the neighbouring workgroups ((NP - 1) / LT of the work per level).
+// Every level's outputs still go to P / out as the single-level kernel writes them (the backward pass reads them).
+// in: the input of the top level i (2^(i+1) samples per line).  grid (lines * 2^(i-NLEV+1) / LT, examples).
+template <int NP, int NLEV>
+struct FwdFused {
+    // stage s = 0 .. NLEV-1 computes level i - s.  NEED[s]: low-pass outputs of stage s the workgroup computes;
+    // C[s]: its first output, relative to (first owned output of the lowest stage) * 2^(NLEV-1-s)
+    static constexpr int need(int s) { return s == NLEV - 1 ? LT : 2 * need(s + 1) + NP - 1; }
+    static constexpr int first(int s) { return s == NLEV - 1 ? 0 : 2 * first(s + 1) + NP / 2 - (NP - 1); }
+    static constexpr int IN = 2 * need(0) + NP - 1;                  // inputs staged
+    static constexpr int IN_FIRST = 2 * first(0) + NP / 2 - (NP - 1);
+    static constexpr int lds_doubles() {
+        int t = IN + 1;
+        for (int s = 0; s < NLEV - 1; s++) t += need(s) + 1;
+        return t;
+    }
+};
+
+template <int NP, int NLEV, int S>
+__device__ __forceinline__ void fwd_fused_stage(const double* src, double* tiles, double* P, double* out, size_t off, int K0, int i,
+                                                const double (&a)[NP], const double (&b)[NP]) {
+    using F = FwdFused<NP, NLEV>;
+    constexpr int NEED = F::need(S), OWN = LT << (NLEV - 1 - S), OWN_OFF = -F::first(S);
+    const int lvl = i - S;
+    const size_t own0 = (size_t)K0 << (NLEV - 1 - S);               // first owned output of this stage, within the line
+    for (int q = threadIdx.x; q < NEED; q += LT) {
+        // the window of output q in ascending order, win[u] = operand of tap NP - 1 - u; the taps are added in the
+        // order of kb_fwd_level_lds, so a level comes out bit for bit as from there
+        const double2* p = reinterpret_cast<const double2*>(src + 2 * q);
+        double win[NP];
+#pragma unroll
+        for (int u = 0; u < NP / 2; u++) { const double2 t = p[u]; win[2 * u] = t.x; win[2 * u + 1] = t.y; }
+        double sl = 0, sh = 0;
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            sl = __builtin_fma(a[j], win[NP - 1 - j], sl);
+            sh = __builtin_fma(b[j], win[NP - 1 - j], sh);
+        }
+        if constexpr (S < NLEV - 1) tiles[q] = sl;
+        const int o = q - OWN_OFF;
+        if (o >= 0 && o < OWN) {
+            P[off + ((size_t)1 << lvl) + own0 + o] = sl;
+            out[off + ((size_t)1 << lvl) + own0 + o] = sh;
+        }
+    }
+    if constexpr (S < NLEV - 1) {
+        __syncthreads();
+        fwd_fused_stage<NP, NLEV, S + 1>(tiles, tiles + NEED + 1, P, out, off, K0, i, a, b);
+    }
+}
+
+template <int NP, int NLEV>
+__global__ __launch_bounds__(LT) void kb_fwd_levels_lds(const double* __restrict__ in, double* __restrict__ P, double* __restrict__ out,
+                                                        size_t xs, Geom g, int i, const FilterDev* filt) {
+    using F = FwdFused<NP, NLEV>;
+    extern __shared__ __attribute__((aligned(16))) double fused_lds[];
+    double a[NP], b[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    const int lgLow = i - (NLEV - 1);                                // outputs per line of the lowest stage: 2^lgLow
+    const int w0 = blockIdx.x * LT;
+    const int line = w0 >> lgLow, K0 = w0 & ((1 << lgLow) - 1);
+    const size_t off = (size_t)blockIdx.y * xs + (size_t)line * g.ls;
+    // inputs (2 << i per line, periodic) from position (K0 << NLEV) + IN_FIRST on
+    const int first = (K0 << NLEV) + F::IN_FIRST, mask = (2 << i) - 1;
+    for (int t = threadIdx.x; t < F::IN + 1; t += LT) fused_lds[t] = in[off + ((first + t) & mask)];
+    __syncthreads();
+    fwd_fused_stage<NP, NLEV, 0>(fused_lds, fused_lds + F::IN + 1, P, out, off, K0, i, a, b);
+}
+
 // kb_bwd_level / kb_grad_level (PROP false) for contiguous lines with at least LT errors per line:
 // grid (workgroups per example <= pgx, examples); a workgroup walks over tiles of LT errors.  The operands of the
 // next tile are fetched into registers while the current one is worked on from LDS, so that a step does not
@@ -823,6 +896,20 @@ int fwd_pass_big(wn_context* ctx, const double* in, double* P, double* out, int 
     const int tail = (g.es == 1 && !g.lanesOnLines && ctx->wave64 && (g.lgLen > TAIL_LG || NP <= 8)) ? std::min(g.lgLen, TAIL_LG) : 0;
     for (int i = g.lgLen - 1; i >= tail; i--) {
         const double* src = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i) * g.es;
+        // long contiguous lines: three (or two) levels per launch while that many are left above the tail
+        if (NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && i - 1 >= tail && (1 << (i - 1)) >= 16 * LT) {
+            const int nlev = (i - 2 >= tail && (1 << (i - 2)) >= 16 * LT) ? 3 : 2;
+            const dim3 grid((1u << (g.lgNL + i - (nlev - 1))) / LT, B);
+            if (nlev == 3) {
+                const size_t lds = FwdFused<NP, 3>::lds_doubles() * sizeof(double);
+                hipLaunchKernelGGL((kb_fwd_levels_lds<NP, 3>), grid, dim3(LT), lds, st, src, P, out, n, g, i, ctx->dfilt);
+            } else {
+                const size_t lds = FwdFused<NP, 2>::lds_doubles() * sizeof(double);
+                hipLaunchKernelGGL((kb_fwd_levels_lds<NP, 2>), grid, dim3(LT), lds, st, src, P, out, n, g, i, ctx->dfilt);
+            }
+            i -= nlev - 1;
+            continue;
+        }
         if (NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && (1 << i) >= LT) {
             hipLaunchKernelGGL(kb_fwd_level_lds<NP>, dim3((1u << (g.lgNL + i)) / LT, B), dim3(LT), 0, st, src,
                                P + (size_t)(1 << i), out + (size_t)(1 << i), n, g, i, ctx->dfilt);
@@ -993,7 +1080,10 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
     WN_HIP(ctx, hipGetLastError());
     if (pending) {
         // the caller looks at the flag when it has queued everything that follows, and starts over if it is up; what the
-        // kernels in between compute from unfinished ranks is arithmetic on garbage, never an address
+        // kernels in between compute from unfinished ranks is arithmetic on garbage, never an address.  The event marks
+        // the point from which the flag is final.
+        if (!ctx->rank_event) WN_HIP(ctx, hipEventCreateWithFlags(&ctx->rank_event, hipEventDisableTiming));
+        WN_HIP(ctx, hipEventRecord(ctx->rank_event, st));
         *pending = flag;
     } else {
         unsigned over = 0;
@@ -1271,9 +1361,13 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         const unsigned* pending = nullptr;
         if ((rc = run_chunk(e0, true, &pending))) return rc;
         if (pending) {
+            // fetched beside the main stream: the host waits for the ranking only, not for the backward pass behind it,
+            // and is back in time to queue the next batch before the GPU runs dry
             unsigned over = 0;
-            WN_HIP(ctx, hipMemcpyAsync(&over, pending, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-            WN_HIP(ctx, hipStreamSynchronize(st));
+            if (!ctx->side_stream) WN_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            WN_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->rank_event, 0));
+            WN_HIP(ctx, hipMemcpyAsync(&over, pending, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->side_stream));
+            WN_HIP(ctx, hipStreamSynchronize(ctx->side_stream));
             if (over) {
                 if (getenv("WAVENET_HIP_VERBOSE"))
                     fprintf(stderr, "wavenet_hip: bucket ranking gave up on a chunk of %d examples of %zu coefficients, radix sort instead\n",
