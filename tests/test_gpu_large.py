@@ -53,7 +53,7 @@ def filt_for(N, seed=0):
 
 @pytest.mark.parametrize("R,C,N", [(128, 64, 4), (64, 128, 2), (8192, 1, 16), (1, 8192, 6), (256, 128, 32), (2, 4096, 8),
                                    (512, 512, 4), (512, 16, 8), (512, 32, 32),
-                                   (1 << 17, 1, 32), (1 << 16, 1, 16)])      # long lines: several levels per launch
+                                   (1 << 17, 1, 32), (1 << 16, 1, 16), (1 << 16, 2, 16)])      # long lines: several levels per launch
 def test_forward_inverse_backprop(ctx, oracle, R, C, N):
     import torch
     B = 2
