@@ -673,14 +673,13 @@ static int train_fused(wn_context* ctx, const double* X, int B, int lgR, int lgC
             grid *= 4;
         } else if ((lgR == 8 || lgR == 9) && lgC == 0 && ctx->NP <= 8 && ctx->wave64) {
             // 1D signals of 256 and 512 samples, up to 8 taps: one wave per example, cascade in registers
-            rc = launch(ctx, wn_kernel_wave1d_line(ctx->NP, 1 << (lgR - 6)), 64, std::max<size_t>((512 + 8) * sizeof(double), wn::TAIL_LDS_BYTES), B, A, &grid, max_slots);
+            rc = launch(ctx, wn_kernel_wave1d_line(ctx->NP, 1 << (lgR - 6)), 64, (512 + 8) * sizeof(double), B, A, &grid, max_slots);
         } else if (lgR == 10 && lgC == 0 && ctx->wave64) {
             // 1D signals of 1024 samples: one wave per example, one example in flight per workgroup
             rc = launch(ctx, wn_kernel_wave1d(ctx->NP), 64, (size_t)(1024 + 64 + 256 + 8 + (ctx->NP == 16 ? 15 * 64 : 0)) * sizeof(double), B, A, &grid, max_slots);
         } else {
             // X, row-stage coefficients (2D only), pyramid, coefficients / sort slots, reduction scratch
-            const size_t shmem = std::max<size_t>(((size_t)(lgC > 0 ? 3 : 2) * R * C + S.NS + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double) + 16,
-                                                  wn::TAIL_LDS_BYTES);
+            const size_t shmem = ((size_t)(lgC > 0 ? 3 : 2) * R * C + S.NS + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double) + 16;
             rc = launch(ctx, fused_kernel(ctx->NP, KIND_TRAIN, sc), S.T, shmem, B, A, &grid, max_slots);
         }
         if (rc) return rc;

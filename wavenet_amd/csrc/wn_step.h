@@ -44,7 +44,10 @@ struct UpdateShared {
 
 // LDS the tail needs at the start of the kernel's dynamic shared memory (every training kernel is done
 // with its own use of it by then)
-constexpr int TAIL_LDS_BYTES = 16 + (MAXTAPS + 2) * 8 + (int)sizeof(UpdateShared) + 16;
+// layout: flag | the sums | UpdateShared | 64 partial results per quantity
+constexpr int TAIL_OFF_SUMS = 16, TAIL_OFF_SHARED = TAIL_OFF_SUMS + (MAXTAPS + 2) * 8;
+constexpr int TAIL_OFF_LSUM = (TAIL_OFF_SHARED + (int)sizeof(UpdateShared) + 15) & ~15;
+constexpr int TAIL_LDS_BYTES = TAIL_OFF_LSUM + (MAXTAPS + 2) * 64 * 8;   // (MAXTAPS + 2 = the doubles of a partial-sum slot)
 
 // The loops of the regularisation terms (wn_costfn.h) for operands in LDS.  This code runs once per step in a
 // single wave, so it pays both for LDS round trips that wait on each other and for every instruction it has
@@ -218,8 +221,8 @@ __device__ __forceinline__ void step_tail(const StepTail& S, const double* parti
     if (!S.ticket) return;   // the same in every thread of the launch
     constexpr int NW = T / 64;
     int* lastp = reinterpret_cast<int*>(lds);
-    double* ssum = reinterpret_cast<double*>(reinterpret_cast<char*>(lds) + 16);
-    UpdateShared& sh = *reinterpret_cast<UpdateShared*>(reinterpret_cast<char*>(lds) + 16 + (MAXTAPS + 2) * 8);
+    double* ssum = reinterpret_cast<double*>(reinterpret_cast<char*>(lds) + TAIL_OFF_SUMS);
+    UpdateShared& sh = *reinterpret_cast<UpdateShared*>(reinterpret_cast<char*>(lds) + TAIL_OFF_SHARED);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slot has left the wave
     __syncthreads();                                    // ... and so has every other wave's of the workgroup
     if (tid == 0) {
@@ -233,13 +236,35 @@ __device__ __forceinline__ void step_tail(const StepTail& S, const double* parti
     }
     __syncthreads();
     if (!*lastp) return;     // the same in every thread of the workgroup
-    const int N = S.filt->N;
+    const int N = S.filt->N, nq = N + 2;
     const int lane = tid & 63, wave = tid >> 6;
-    for (int q = wave; q <= N + 1; q += NW) {
-        const double s = reduce_slots(partial, nslots, stride, q, lane);
-        if (lane == 0) { ssum[q] = s; S.sums[q] = s; }
+    // The order of reduce_slots (slots l, l + 64, ... in order, then the 64 partial results by a shuffle tree), computed
+    // from whole rows as k_finish does: a thread owns (l, quantity) pairs, consecutive threads consecutive quantities
+    // of a slot, so the slots are read as rows and not as one cache line per lane and quantity.
+    double (*lsum)[64] = reinterpret_cast<double (*)[64]>(reinterpret_cast<char*>(lds) + TAIL_OFF_LSUM);
+    for (int pair = tid; pair < 64 * nq; pair += T) {
+        const int l = pair / nq, q = pair - l * nq;
+        double s = 0;
+        for (int base = l; base < nslots; base += 64 * 16) {
+            double v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int slot = base + 64 * i;
+                v[i] = (slot < nslots) ? partial[(size_t)slot * stride + q] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (base + 64 * i < nslots) s += v[i];
+            }
+        }
+        lsum[q][l] = s;
     }
     if (tid == 0) __hip_atomic_store(S.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+    __syncthreads();
+    for (int q = wave; q < nq; q += NW) {
+        const double s = wave_sum(lsum[q][lane]);
+        if (lane == 0) { ssum[q] = s; S.sums[q] = s; }
+    }
     __syncthreads();
     if (S.mode == 2) update_body(S.filt, ssum, S.P, sh, tid);
 }
