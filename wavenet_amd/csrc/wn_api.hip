@@ -148,7 +148,8 @@ __global__ __launch_bounds__(64) void k_reduce_partials(const double* partial, i
 // after an all-reduce over ranks, and for examples that take the streamed path (wn_step.h has the body).
 __global__ __launch_bounds__(64) void k_update(wn::FilterDev* f, const double* sums, wn::UpdateParams P) {
     __shared__ wn::UpdateShared sh;
-    wn::update_body(f, sums, P, sh, (int)threadIdx.x);
+    const wn::UpdateInputs state(f, (int)threadIdx.x);
+    wn::update_body(f, state, sums, P, sh, (int)threadIdx.x);
 }
 
 // Batch reduction and update in one launch, for the training kernels whose many small workgroups leave too
@@ -160,7 +161,8 @@ __global__ __launch_bounds__(1024) void k_finish(const double* partial, int nslo
     __shared__ double lsum[wn::PSTRIDE][64];
     __shared__ wn::UpdateShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = S.filt->N, nq = N + 2;
+    const wn::UpdateInputs state(S.filt, tid);     // on its way while the slots are added up
+    const int N = state.N, nq = N + 2;
     // The sums in the order of reduce_slots (slots l, l + 64, ... added up in order, then the 64 partial results by
     // a shuffle tree), computed from whole rows: a thread owns (l, quantity) pairs with consecutive threads on
     // consecutive quantities of a slot, so the slots are read as rows, not as one cache line per lane and quantity.
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(1024) void k_finish(const double* partial, int nslo
         if (lane == 0) { ssum[q] = s; S.sums[q] = s; }
     }
     __syncthreads();
-    if (S.mode == 2) wn::update_body(S.filt, ssum, S.P, sh, tid);
+    if (S.mode == 2) wn::update_body(S.filt, state, ssum, S.P, sh, tid);
 }
 
 __global__ void k_reset_steps(wn::FilterDev* f) {

@@ -100,12 +100,25 @@ __device__ __forceinline__ double add_lag_terms(double regd, const double* pref,
 // A batch whose sums, new filter or cost are not finite is not applied (the reference's train() fails
 // before anything is queued, src/Wavenet.cxx:234-241), and neither is any batch after it: the flag
 // stays up until the host takes it down.
-__device__ inline void update_body(FilterDev* f, const double* sums, const UpdateParams& P, UpdateShared& sh, int t) {
-    const int N = f->N;
-    // everything the update reads from memory, in one round trip
-    const int was_bad = f->nonfinite, steps = f->steps, dpad = f->d;
-    const double a_mine = (t < N) ? f->a_true[t] : 0.0, p_mine = (t < N) ? f->momentum[t] : 0.0;
-    const double a_margin = (t >= MAXTAPS && t < MAXTAPS + N) ? f->a_true[t - MAXTAPS] : 0.0;
+// Everything the update reads from the filter state, fetched in one round trip (and, by the callers that have
+// something else to wait for first, before that).
+struct UpdateInputs {
+    int N, was_bad, steps, dpad;
+    double a_mine, p_mine, a_margin;
+    __device__ __forceinline__ UpdateInputs(const FilterDev* f, int t) {
+        N = f->N;
+        was_bad = f->nonfinite;
+        steps = f->steps;
+        dpad = f->d;
+        a_mine = (t < N) ? f->a_true[t] : 0.0;
+        p_mine = (t < N) ? f->momentum[t] : 0.0;
+        a_margin = (t >= MAXTAPS && t < MAXTAPS + N) ? f->a_true[t - MAXTAPS] : 0.0;
+    }
+};
+
+__device__ inline void update_body(FilterDev* f, const UpdateInputs& in, const double* sums, const UpdateParams& P, UpdateShared& sh, int t) {
+    const int N = in.N, was_bad = in.was_bad, steps = in.steps, dpad = in.dpad;
+    const double a_mine = in.a_mine, p_mine = in.p_mine, a_margin = in.a_margin;
     if (t == 0) sh.bad = was_bad;
     __syncthreads();
     if (t < 64) {
@@ -236,7 +249,8 @@ __device__ __forceinline__ void step_tail(const StepTail& S, const double* parti
     }
     __syncthreads();
     if (!*lastp) return;     // the same in every thread of the workgroup
-    const int N = S.filt->N, nq = N + 2;
+    const UpdateInputs state(S.filt, tid);     // on its way while the slots are added up
+    const int N = state.N, nq = N + 2;
     const int lane = tid & 63, wave = tid >> 6;
     // The order of reduce_slots (slots l, l + 64, ... in order, then the 64 partial results by a shuffle tree), computed
     // from whole rows as k_finish does: a thread owns (l, quantity) pairs, consecutive threads consecutive quantities
@@ -266,7 +280,7 @@ __device__ __forceinline__ void step_tail(const StepTail& S, const double* parti
         if (lane == 0) { ssum[q] = s; S.sums[q] = s; }
     }
     __syncthreads();
-    if (S.mode == 2) update_body(S.filt, ssum, S.P, sh, tid);
+    if (S.mode == 2) update_body(S.filt, state, ssum, S.P, sh, tid);
 }
 
 }  // namespace wn
