@@ -1,9 +1,12 @@
 // Streamed path for examples that do not fit the LDS-resident kernels (R*C > 4096), e.g. 512x512
-// images and 2^20-sample signals.  Every level of the cascade is one kernel over a chunk of the
-// batch; pyramids, coefficients and errors live in a device workspace (288 GB of HBM make that
-// cheap), the Gini ranks come from stable device-wide radix sorts (one sort of 32-bit keys per slice of
-// the chunk plus an exact re-ranking of equal-key groups, see gini_large; two sorts on 64-bit keys as
-// the fallback), and all reductions are two-stage and ordered (no atomics).
+// images and 2^20-sample signals.  Pyramids, coefficients and errors live in a device workspace (288 GB of
+// HBM make that cheap).  Lines of 128 .. 1024 samples run through the one-wave-per-line kernels of wn_lines.h;
+// every other length level by level, one kernel per level (or per two or three levels) over a chunk of the batch,
+// with the levels below 4096 samples of a contiguous line in one launch.  The Gini ranks come from the per-example
+// bucket ranking of wn_rank.h; when that gives up on a chunk (too many magnitudes crowd into one bucket) from
+// stable device-wide radix sorts (one sort of 32-bit keys per slice of the chunk plus an exact re-ranking of
+// equal-key groups, see gini_large; two sorts on 64-bit keys behind that).  All reductions of data are two-stage
+// and ordered (atomics only on counters, cursors and maxima).
 //
 // Reference stages: forward_ (src/Wavenet.cxx:404-445, 562-622), SparseTerm(Deriv)
 // (src/CostFunctions.cxx:6-117), backpropagate_ (src/Wavenet.cxx:474-556, 665-711).

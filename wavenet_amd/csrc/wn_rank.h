@@ -15,7 +15,8 @@
 //                own magnitude range linearly, exact (magnitude, index) comparison inside a sub-bin, the rank
 //                written to the coefficient's home position, and the bucket's share of the two Gini sums from
 //                the magnitudes in sorted order;
-//   5. kr_finish adds the buckets' shares per example in bucket order.
+//   5. kr_finish adds the buckets' shares per example: lane l of a wave takes buckets l, l + 64, ... in order, the lanes are
+//                combined by a butterfly.
 // Exact zeros are left out (they rank first and need no rank of their own).  Every rank is decided by exact
 // comparisons, so the result does not depend on the order in which atomics land; every sum is taken in a fixed
 // order.  A bucket that would hold more than RK_CAP magnitudes (thousands of coefficients within half a percent
