@@ -94,12 +94,6 @@ __device__ __forceinline__ double add_lag_terms(double regd, const double* pref,
     return regd;
 }
 
-// Wavenet::flushBatchQueue_ / update_ / setFilter (src/Wavenet.cxx:717-765, 8-36) from the batch's sums.
-// Called by every thread of the workgroup (uniformly); threads 0..63 do the work: lane l evaluates lag
-// m = l - N/2 of the regularisation sums, lane i adds them up for tap i in the reference's order.
-// A batch whose sums, new filter or cost are not finite is not applied (the reference's train() fails
-// before anything is queued, src/Wavenet.cxx:234-241), and neither is any batch after it: the flag
-// stays up until the host takes it down.
 // Everything the update reads from the filter state, fetched in one round trip (and, by the callers that have
 // something else to wait for first, before that).
 struct UpdateInputs {
@@ -116,6 +110,12 @@ struct UpdateInputs {
     }
 };
 
+// Wavenet::flushBatchQueue_ / update_ / setFilter (src/Wavenet.cxx:717-765, 8-36) from the batch's sums.
+// Called by every thread of the workgroup (uniformly); threads 0..63 do the work: lane l evaluates lag
+// m = l - N/2 of the regularisation sums, lane i adds them up for tap i in the reference's order.
+// A batch whose sums, new filter or cost are not finite is not applied (the reference's train() fails
+// before anything is queued, src/Wavenet.cxx:234-241), and neither is any batch after it: the flag
+// stays up until the host takes it down.
 __device__ inline void update_body(FilterDev* f, const UpdateInputs& in, const double* sums, const UpdateParams& P, UpdateShared& sh, int t) {
     const int N = in.N, was_bad = in.was_bad, steps = in.steps, dpad = in.dpad;
     const double a_mine = in.a_mine, p_mine = in.p_mine, a_margin = in.a_margin;
