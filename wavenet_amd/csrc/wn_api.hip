@@ -670,9 +670,8 @@ static int train_fused(wn_context* ctx, const double* X, int B, int lgR, int lgC
         const bool prof = ctx->prof_used < (int)ctx->prof_begin.size();
         if (prof) WN_HIP(ctx, hipEventRecord(ctx->prof_begin[ctx->prof_used], ctx->stream));
         if (wave64) {
-            // one wave per example, four examples per workgroup; one partial-sum slot per wave
-            rc = launch(ctx, wave64, 256, (size_t)4 * wn::W64_TILE * sizeof(double), (B + 3) / 4, A, &grid, max_slots / 4);
-            grid *= 4;
+            // one wave per example, four examples per workgroup; one partial-sum slot per workgroup
+            rc = launch(ctx, wave64, 256, (size_t)4 * wn::W64_TILE * sizeof(double), (B + 3) / 4, A, &grid, max_slots);
         } else if ((lgR == 8 || lgR == 9) && lgC == 0 && ctx->NP <= 8 && ctx->wave64) {
             // 1D signals of 256 and 512 samples, up to 8 taps: one wave per example, cascade in registers
             rc = launch(ctx, wn_kernel_wave1d_line(ctx->NP, 1 << (lgR - 6)), 64, (512 + 8) * sizeof(double), B, A, &grid, max_slots);

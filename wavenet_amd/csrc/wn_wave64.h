@@ -721,15 +721,25 @@ __global__ __launch_bounds__(256, 1) void k_train64(FusedArgs A) {
             if (A.S) A.S[e] = S;
         }
     }
-    // per-wave sums: slot = workgroup * 4 + wave
+    // The four waves' running sums are added in wave order and leave as one slot per workgroup: the reduction at
+    // the end of the step then has a quarter of the slots to read.
     double bad = accBad;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, 64);
-    double* part = A.partial + (size_t)(blockIdx.x * 4 + wave) * PSTRIDE;
+    __syncthreads();                                    // every wave is done with the tiles
+    double* wsum = smem + (size_t)wave * PSTRIDE;       // [4][PSTRIDE]
     const int k = lane - dpad;
-    if (lane < NP && k >= 0 && k < N) store_partial(part + k, accG);
-    if (lane == 0) { store_partial(part + N, accS); store_partial(part + N + 1, bad); }
-    step_tail<256>(A.tail, A.partial, (int)gridDim.x * 4, PSTRIDE, smem, (int)threadIdx.x);
+    if (lane < NP && k >= 0 && k < N) wsum[k] = accG;
+    if (lane == 0) { wsum[N] = accS; wsum[N + 1] = bad; }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid <= N + 1) {
+        double s = smem[tid];
+#pragma unroll
+        for (int w = 1; w < 4; w++) s += smem[w * PSTRIDE + tid];
+        store_partial(A.partial + (size_t)blockIdx.x * PSTRIDE + tid, s);
+    }
+    step_tail<256>(A.tail, A.partial, (int)gridDim.x, PSTRIDE, smem + 4 * PSTRIDE, tid);
 }
 
 }  // namespace wn
