@@ -1,6 +1,6 @@
-// The end of a training step inside the training kernel (k_train64: at most 1024 partial-sum slots, which one
+// The end of a training step inside the training kernel (k_train64: at most 256 partial-sum slots, which one
 // workgroup adds up in a few microseconds): the workgroup that finishes last adds up the
-// per-wave partial sums and, on a single GPU, applies the filter update, so that a whole step
+// per-workgroup partial sums and, on a single GPU, applies the filter update, so that a whole step
 // (src/Wavenet.cxx:184-242 for a batch, then flushBatchQueue_ / update_ / setFilter, :717-765, 8-36) is
 // ONE kernel launch and consecutive batches queue up on the stream with no host code in between.
 //
