@@ -4,8 +4,8 @@
 // (src/Wavenet.cxx:184-242 for a batch, then flushBatchQueue_ / update_ / setFilter, :717-765, 8-36) is
 // ONE kernel launch and consecutive batches queue up on the stream with no host code in between.
 //
-// Hand-over between workgroups: every wave stores its slot write-through (agent-scope stores) and waits
-// for the stores to complete, the workgroup meets at a barrier, one lane takes a ticket from a device-wide
+// Hand-over between workgroups: a workgroup stores its slot write-through (agent-scope stores), its waves wait
+// for their stores to complete and meet at a barrier, one lane takes a ticket from a device-wide
 // counter; the workgroup whose ticket is the last one acquires at agent scope and only then reads
 // the other workgroups' slots.  Nothing ever waits for another workgroup, so no placement or
 // residency assumption is made.
