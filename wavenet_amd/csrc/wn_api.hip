@@ -661,9 +661,10 @@ static int train_fused(wn_context* ctx, const double* X, int B, int lgR, int lgC
     A.B = B; A.lgR = lgR; A.lgC = lgC; A.filt = ctx->dfilt;
     A.X = X; A.grad = grad; A.S = Sout; A.partial = partial;
     const void* wave64 = (lgR == 6 && lgC == 6 && ctx->wave64) ? wn_kernel_wave64(ctx->NP) : nullptr;
-    // k_train64's last workgroup ends the step itself (wn_step.h); the kernels of many small workgroups
-    // leave that to k_finish
-    const bool in_kernel_tail = tail && B > 0 && wave64;
+    const bool wave1d = !wave64 && lgR == 10 && lgC == 0 && ctx->wave64;
+    // the last workgroup of k_train64 and of k_train1d1024 ends the step itself (wn_step.h); the kernels of many
+    // small workgroups leave that to k_finish
+    const bool in_kernel_tail = tail && B > 0 && (wave64 || wave1d);
     if (in_kernel_tail) A.tail = *tail;
     int grid = 0, rc = WN_OK;
     if (B > 0) {
@@ -675,9 +676,11 @@ static int train_fused(wn_context* ctx, const double* X, int B, int lgR, int lgC
         } else if ((lgR == 8 || lgR == 9) && lgC == 0 && ctx->NP <= 8 && ctx->wave64) {
             // 1D signals of 256 and 512 samples, up to 8 taps: one wave per example, cascade in registers
             rc = launch(ctx, wn_kernel_wave1d_line(ctx->NP, 1 << (lgR - 6)), 64, (512 + 8) * sizeof(double), B, A, &grid, max_slots);
-        } else if (lgR == 10 && lgC == 0 && ctx->wave64) {
-            // 1D signals of 1024 samples: one wave per example, one example in flight per workgroup
-            rc = launch(ctx, wn_kernel_wave1d(ctx->NP), 64, (size_t)(1024 + 64 + 256 + 8 + (ctx->NP == 16 ? 15 * 64 : 0)) * sizeof(double), B, A, &grid, max_slots);
+        } else if (wave1d) {
+            // 1D signals of 1024 samples: one wave per example, four examples per workgroup (an LDS slice per wave);
+            // one partial-sum slot per workgroup
+            rc = launch(ctx, wn_kernel_wave1d(ctx->NP), 256, (size_t)4 * (1024 + 64 + 256 + 8 + (ctx->NP == 16 ? 15 * 64 : 0)) * sizeof(double),
+                        (B + 3) / 4, A, &grid, max_slots);
         } else {
             // X, row-stage coefficients (2D only), pyramid, coefficients / sort slots, reduction scratch
             const size_t shmem = ((size_t)(lgC > 0 ? 3 : 2) * R * C + S.NS + (size_t)(S.T / 64) * ctx->NP + 2) * sizeof(double) + 16;

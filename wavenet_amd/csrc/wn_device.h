@@ -495,19 +495,33 @@ __device__ __forceinline__ void sort_cross_merges(double (&v)[1 << Q], double* k
     }
 }
 
+// Meeting point of the threads that work on one example.  WAVE: they are one wave, which is only one of several in
+// its workgroup (each on an example of its own, so a workgroup barrier would wait for waves that never come): a
+// wave's LDS operations execute in order, all it takes is that the compiler keeps them in order too.
+template <bool WAVE>
+__device__ __forceinline__ void group_sync() {
+    if constexpr (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
 // Sorts T*K keys: v[r] is key t*K + r on entry; on exit keys[e] holds the e-th smallest.
-template <int LGN, int Q>
+template <int LGN, int Q, bool WAVE = false>
 __device__ __forceinline__ void sort_full(double (&v)[1 << Q], double* keys, unsigned t) {
+    static_assert(!WAVE || LGN == Q + 6, "one wave sorts its own keys without a workgroup barrier");
     constexpr int K = 1 << Q;
     constexpr int WL = Q + 6;
     const int lane = (int)(t & 63u);
     sort_regs<Q>(v);
     sort_wave_merges<LGN, Q, Q + 1>(v, lane);
     sort_cross_merges<LGN, Q, WL + 1>(v, keys, t, lane);
-    __syncthreads();
+    group_sync<WAVE>();
 #pragma unroll
     for (int r = 0; r < K; r++) keys[t * K + r] = v[r];  // final order is stored unswizzled
-    __syncthreads();
+    group_sync<WAVE>();
 }
 
 // Number of keys strictly below v in the sorted buffer (v itself is in the buffer).
@@ -539,10 +553,11 @@ __device__ __forceinline__ double sign_ref(double x) {
 // bufY holds the n coefficients in vectorise (column-major) order and T*K slots; on exit it
 // holds delta in the same order when WRITE_DELTA.  Ranks of equal non-zero magnitudes
 // ascend with the index (the reference's std::sort leaves that order unspecified).
-// Returns S in every thread.  `red` needs T/64 doubles, `flag` one int.
+// Returns S in every thread.  `red` needs T/64 doubles, `flag` one int.  WAVE: see group_sync (tid is then the lane).
 // ---------------------------------------------------------------------------------------------
-template <int T, int Q, bool WRITE_DELTA>
+template <int T, int Q, bool WRITE_DELTA, bool WAVE = false>
 __device__ __forceinline__ double gini_phase(double* bufY, int n, double* red, int* flag, int tid) {
+    static_assert(!WAVE || T == 64, "WAVE: one wave per example");
     constexpr int K = 1 << Q;
     constexpr int LGN = __builtin_ctz(T) + Q;
     double yv[K], kv[K];
@@ -554,12 +569,12 @@ __device__ __forceinline__ double gini_phase(double* bufY, int n, double* red, i
         kv[r] = (e < (unsigned)n) ? __builtin_fabs(yv[r]) : __builtin_inf();
     }
     if (tid == 0) *flag = 0;
-    __syncthreads();
+    group_sync<WAVE>();
     {
         double sv[K];
 #pragma unroll
         for (int r = 0; r < K; r++) sv[r] = kv[r];
-        sort_full<LGN, Q>(sv, bufY, (unsigned)tid);
+        sort_full<LGN, Q, WAVE>(sv, bufY, (unsigned)tid);
     }
 
     unsigned lb[K];
@@ -573,7 +588,7 @@ __device__ __forceinline__ double gini_phase(double* bufY, int n, double* red, i
         }
     }
     if (tie) *flag = 1;
-    __syncthreads();
+    group_sync<WAVE>();
     if (*flag) {
         // Rare path: some non-zero magnitudes are equal.  Each tied group [lb, ub) of the
         // sorted buffer is reused as scratch: 32-bit word 0 counts members, words 1..mult list
@@ -589,12 +604,12 @@ __device__ __forceinline__ double gini_phase(double* bufY, int n, double* red, i
                 do { ub[r]++; } while (ub[r] < (1u << LGN) && bufY[ub[r]] == kv[r]);
             }
         }
-        __syncthreads();
+        group_sync<WAVE>();
 #pragma unroll
         for (int r = 0; r < K; r++) {
             if (mine[r]) words[2 * lb[r]] = 0u;
         }
-        __syncthreads();
+        group_sync<WAVE>();
 #pragma unroll
         for (int r = 0; r < K; r++) {
             if (mine[r]) {
@@ -602,7 +617,7 @@ __device__ __forceinline__ double gini_phase(double* bufY, int n, double* red, i
                 words[2 * lb[r] + slot] = e0 + r;
             }
         }
-        __syncthreads();
+        group_sync<WAVE>();
 #pragma unroll
         for (int r = 0; r < K; r++) {
             if (mine[r]) {
@@ -632,7 +647,7 @@ __device__ __forceinline__ double gini_phase(double* bufY, int n, double* red, i
     const double g = (double)n * sabs;
     if constexpr (WRITE_DELTA) {
         const double inv_g2 = 1.0 / (g * g);
-        __syncthreads();
+        group_sync<WAVE>();
 #pragma unroll
         for (int r = 0; r < K; r++) {
             if (e0 + r < (unsigned)n) {
@@ -642,7 +657,7 @@ __device__ __forceinline__ double gini_phase(double* bufY, int n, double* red, i
                 bufY[e0 + r] = -(df * g - f * dg) * inv_g2;
             }
         }
-        __syncthreads();
+        group_sync<WAVE>();
     }
     return 1.0 - f / g;
 }

@@ -418,20 +418,29 @@ __device__ __forceinline__ bool w1d_gini_fast(const double (&y)[16], double* buf
 }
 
 // The general Gini phase as a call of its own: inlined, its registers would add to those the fast path holds.
+// (WAVE: this wave is one of four in its workgroup, each with an example of its own)
 __device__ __attribute__((noinline)) double w1d_gini_general(double* bufY, double* red, int* flag, int lane) {
-    return gini_phase<64, 4, true>(bufY, 1024, red, flag, lane);
+    return gini_phase<64, 4, true, true>(bufY, 1024, red, flag, lane);
 }
 
+// doubles of LDS per wave: sort exchange buffer / coefficients and errors, ranks, scratch of the general Gini phase,
+// and with 16 taps the parked pyramid
+template <int NP>
+constexpr int w1d_lds_doubles() { return W1D_SORT_DOUBLES + 256 + 8 + (NP == 16 ? 15 * 64 : 0); }
+
 // ---- kernel -------------------------------------------------------------------------------------------
-// 64 threads = one wave = one example in flight per workgroup; grid-stride over the batch.
+// 256 threads = 4 waves = 4 examples in flight per workgroup, each wave with an LDS slice of its own and no barrier
+// between them until the end; grid-stride over the batch.  (Four waves per workgroup rather than one so that the
+// partial sums leave as one slot per workgroup and the workgroup that finishes last can end the step, wn_step.h.)
 #ifndef W1D_WAVES
 #define W1D_WAVES (NP > 16 ? 1 : 2)
 #endif
 template <int NP>
-__global__ __launch_bounds__(64, W1D_WAVES) void k_train1d1024(FusedArgs A) {
+__global__ __launch_bounds__(256, W1D_WAVES) void k_train1d1024(FusedArgs A) {
     constexpr int n = 1024;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* bufY = smem;                       // sort exchange buffer; 1024 coefficients / errors in coefficient order
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* bufY = smem + (size_t)wave * w1d_lds_doubles<NP>();   // sort exchange buffer; 1024 coefficients / errors in coefficient order
     unsigned short* rk = reinterpret_cast<unsigned short*>(bufY + W1D_SORT_DOUBLES);   // ranks by coefficient index
     double* red = bufY + W1D_SORT_DOUBLES + 256;    // scratch of the general Gini phase
     int* flag = reinterpret_cast<int*>(red + 4);
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(64, W1D_WAVES) void k_train1d1024(FusedArgs A) {
     // pass wants it, and the kernel then runs two waves per SIMD with few spills instead of one (measured: 7 % faster)
     constexpr bool PARK = (NP == 16);
     double* park = red + 8;
-    const int lane0 = threadIdx.x;
+    const int lane0 = threadIdx.x & 63;
     const FilterDev* filt = A.filt;
     double a[NP], b[NP];
 #pragma unroll
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(64, W1D_WAVES) void k_train1d1024(FusedArgs A) {
     const int N = filt->N, dpad = filt->d;
 
     double accG = 0, accS = 0, accBad = 0;
-    for (int e = blockIdx.x; e < A.B; e += gridDim.x) {
+    for (int e = blockIdx.x * 4 + wave; e < A.B; e += gridDim.x * 4) {
         // The lane number as a value the compiler cannot see through: the LDS and cross-lane addresses derived
         // from it are then computed where they are used, not all held in registers across the whole loop.
         int lane = lane0;
@@ -464,7 +473,7 @@ __global__ __launch_bounds__(64, W1D_WAVES) void k_train1d1024(FusedArgs A) {
 #pragma unroll
             for (int i = 0; i < 8; i++) { const double2 t = src[i]; x[2 * i] = t.x; x[2 * i + 1] = t.y; }
         }
-        __syncthreads();   // the previous example's errors have been read
+        group_sync<true>();   // the previous example's errors have been read
         double y[16];      // the lane's coefficients, slot s = coefficient w1d_coef_index(lane, s)
         w1d_fwd_block<NP, 16>(x, lo9, hi, a, b, lane);
 #pragma unroll
@@ -527,7 +536,7 @@ __global__ __launch_bounds__(64, W1D_WAVES) void k_train1d1024(FusedArgs A) {
             bufY[128 + 2 * lane + 1] = y[13];
             bufY[64 + lane] = y[14];
             bufY[lane] = y[15];
-            __syncthreads();
+            group_sync<true>();
             S = w1d_gini_general(bufY, red, flag, lane);
         }
 
@@ -593,13 +602,25 @@ __global__ __launch_bounds__(64, W1D_WAVES) void k_train1d1024(FusedArgs A) {
             if (A.S) A.S[e] = S;
         }
     }
+    // The four waves' running sums are added in wave order and leave as one slot per workgroup; the workgroup
+    // that finishes last ends the step (step_tail).
     double bad = accBad;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, 64);
-    double* part = A.partial + (size_t)blockIdx.x * PSTRIDE;
+    __syncthreads();                                    // every wave is done with its slice
+    double* wsum = smem + (size_t)wave * PSTRIDE;       // [4][PSTRIDE]
     const int k = lane0 - dpad;
-    if (lane0 < NP && k >= 0 && k < N) part[k] = accG;
-    if (lane0 == 0) { part[N] = accS; part[N + 1] = bad; }
+    if (lane0 < NP && k >= 0 && k < N) wsum[k] = accG;
+    if (lane0 == 0) { wsum[N] = accS; wsum[N + 1] = bad; }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid <= N + 1) {
+        double s = smem[tid];
+#pragma unroll
+        for (int w = 1; w < 4; w++) s += smem[w * PSTRIDE + tid];
+        store_partial(A.partial + (size_t)blockIdx.x * PSTRIDE + tid, s);
+    }
+    step_tail<256>(A.tail, A.partial, (int)gridDim.x, PSTRIDE, smem + 4 * PSTRIDE, tid);
 }
 
 }  // namespace wn
