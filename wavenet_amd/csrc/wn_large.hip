@@ -1305,7 +1305,7 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
             if (counts) WN_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)Bc * (n / CP_BLOCK) * sizeof(unsigned), st));
             if (kmaxArg) WN_HIP(ctx, hipMemsetAsync(kmaxArg, 0, (size_t)(Bc + 16) * sizeof(unsigned), st));   // and the ranking's flag behind them
             void* args[] = {(void*)&y1c, (void*)&YD, (void*)&pcolArg, (void*)&xs, (void*)&ncols, (void*)&dfilt, (void*)&counts, (void*)&kmaxArg};
-            WN_HIP(ctx, hipLaunchKernel(line_kernel(NP, LN_FWD_COLS, Mcol), dim3(std::min(C, LN_GX), Bc), dim3(64), args, 0, st));
+            WN_HIP(ctx, hipLaunchKernel(line_kernel(NP, LN_FWD_COLS, Mcol), dim3((std::min(C, LN_GX) + 3) / 4, Bc), dim3(256), args, 0, st));
         } else if ((rc = fwd_pass_big<NP>(ctx, Y1, Pcol, YD, Bc, n, cg))) {
             return rc;
         }
@@ -1334,8 +1334,8 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
             int slice = rank_slice ? rank_slice : 1;
             void* args[] = {(void*)&Yc, (void*)&y1c, (void*)&out, (void*)&xs, (void*)&ncols, (void*)&dfilt, (void*)&partial,
                             (void*)&ranks, (void*)&slice, (void*)&fg};
-            WN_HIP(ctx, hipLaunchKernel(line_kernel(NP, rank_slice ? LN_BWD_COLS_RANKS : LN_BWD_COLS, Mcol), dim3(std::min(C, LN_GX), Bc),
-                                        dim3(64), args, 0, st));
+            WN_HIP(ctx, hipLaunchKernel(line_kernel(NP, rank_slice ? LN_BWD_COLS_RANKS : LN_BWD_COLS, Mcol),
+                                        dim3((std::min(C, LN_GX) + 3) / 4, Bc), dim3(256), args, 0, st));
             D1 = pl.A;
         } else if ((rc = bwd_pass_big<NP>(ctx, YD, Y1, Pcol, pl.A, pl.Bb, Bc, n, cg, lgC > 0, pl.partial, pgx, &D1, Yout ? nullptr : YD))) {
             return rc;

@@ -165,20 +165,22 @@ __device__ __forceinline__ int ln_opaque(int v) {
 }
 
 // ---- columns: contiguous lines of 64 M samples ---------------------------------------------------------
-// grid (workgroups per example, examples), 64 threads.  in/Y/P: chunk arrays, example stride xs, column c
+// grid (workgroups per example, examples), 256 threads = 4 waves, each on columns of its own.  in/Y/P: chunk arrays, example stride xs, column c
 // of an example at c * 64 M.  P may be null.  counts (may be null): counts[i] receives (is added) the number
 // of non-zero coefficients among the chunk's coefficients [2048 i, 2048 (i + 1)) -- what the streamed Gini
 // phase needs first, gathered while the coefficients are still in registers.  kmax (may be null): kmax[example]
 // is raised to the largest exponent word among the example's coefficients.
 template <int NP, int M>
-__global__ LN_BOUNDS(64) void kc_fwd_cols(const double* __restrict__ in, double* __restrict__ Y, double* __restrict__ P, size_t xs,
-                                          int ncols, const FilterDev* filt, unsigned* counts, unsigned* kmax) {
-    const int lane0 = threadIdx.x;
+__global__ LN_BOUNDS(256) void kc_fwd_cols(const double* __restrict__ in, double* __restrict__ Y, double* __restrict__ P, size_t xs,
+                                           int ncols, const FilterDev* filt, unsigned* counts, unsigned* kmax) {
+    // four independent waves per workgroup (one per SIMD: waves of one-wave workgroups are not spread as evenly)
+    const int lane0 = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6), nslots = gridDim.x * 4;
     double a[NP], b[NP];
     ln_load_taps<NP>(filt, a, b);
     const size_t off = (size_t)blockIdx.y * xs;
     unsigned kmine = 0;
-    for (int c = blockIdx.x; c < ncols; c += gridDim.x) {
+    for (int c = slot; c < ncols; c += nslots) {
         const int lane = ln_opaque(lane0);
         const size_t lo = off + (size_t)c * (64 * M);
         LinePyramid<M> p;
@@ -214,10 +216,12 @@ __global__ LN_BOUNDS(64) void kc_fwd_cols(const double* __restrict__ in, double*
 // ranks: per slice of `slice` examples an array of slice * n ranks at ranks + slice_first_example * n
 // DOUBLES (the streamed path's layout).
 template <int NP, int M, bool FROM_RANKS>
-__global__ LN_BOUNDS(64) void kc_bwd_cols(const double* __restrict__ coef, const double* __restrict__ in, double* __restrict__ out,
-                                          size_t xs, int ncols, const FilterDev* filt, double* partial, const double* ranks,
-                                          int slice, const double* fg) {
-    const int lane0 = threadIdx.x;
+__global__ LN_BOUNDS(256) void kc_bwd_cols(const double* __restrict__ coef, const double* __restrict__ in, double* __restrict__ out,
+                                           size_t xs, int ncols, const FilterDev* filt, double* partial, const double* ranks,
+                                           int slice, const double* fg) {
+    // four independent waves per workgroup, each with a partial-sum slot of its own (grid.x * 4 <= LN_GX)
+    const int lane0 = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6), nslots = gridDim.x * 4;
     double a[NP], b[NP];
     ln_load_taps<NP>(filt, a, b);
     double gL[NP], gH[NP];
@@ -233,7 +237,7 @@ __global__ LN_BOUNDS(64) void kc_bwd_cols(const double* __restrict__ coef, const
         gini.g = fg[2 * e + 1];
         gini.inv_g2 = 1.0 / (gini.g * gini.g);
     }
-    for (int c = blockIdx.x; c < ncols; c += gridDim.x) {
+    for (int c = slot; c < ncols; c += nslots) {
         const int lane = ln_opaque(lane0);
         const size_t lo = off + (size_t)c * (64 * M);
         LinePyramid<M> p;
@@ -260,7 +264,7 @@ __global__ LN_BOUNDS(64) void kc_bwd_cols(const double* __restrict__ coef, const
             ln_backward<NP, M, false>(p, dy, dtop, a, b, gL, gH, lane);
         }
     }
-    double* part = partial + ((size_t)blockIdx.y * LN_GX + blockIdx.x) * 2 * NP;
+    double* part = partial + ((size_t)blockIdx.y * LN_GX + slot) * 2 * NP;
 #pragma unroll
     for (int u = 0; u < NP; u++) {
         double sl = gL[u], sh = gH[u];
