@@ -1076,9 +1076,19 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
     if (G > 1) WN_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)B * NF * sizeof(unsigned), st));
     hipLaunchKernelGGL(kr_hist, dim3(G, B), dim3(RK_PT), (size_t)NF * 4, st, Y, n, kmax, hist, NF, lgBPO);
     hipLaunchKernelGGL(kr_scan, dim3(B), dim3(RK_BT), (size_t)NF * 4, st, hist, kmax, NF, lgBPO, n, btab, meta, flag);
-    if (G == 1) hipLaunchKernelGGL(kr_part<true>, dim3(1, B), dim3(RK_PT), (size_t)NF * 2, st, Y, n, btab, meta, NF, lgBPO, mag, idxA, flag);
-    else hipLaunchKernelGGL(kr_part<false>, dim3(G, B), dim3(RK_PT), (size_t)NF * 2, st, Y, n, btab, meta, NF, lgBPO, mag, idxA, flag);
-    hipLaunchKernelGGL(kr_bucket, dim3((unsigned)nbmax * (((unsigned)B + 7u) & ~7u)), dim3(RK_KT), 0, st, mag, idxA, n, meta, rank, B, flag, NF, lgBPO);
+    const int sub = ctx->rank_sub > 0 ? std::min(ctx->rank_sub, B) : B;
+    for (int s0 = 0; s0 < B; s0 += sub) {
+        const int Bs = std::min(sub, B - s0);
+        int Gs = 1;
+        while ((long long)Gs * Bs < 2LL * ctx->numCU && n / (2 * (size_t)Gs) >= (size_t)RK_TILE) Gs *= 2;
+        const double* Ys = Y + (size_t)s0 * n;
+        const unsigned short* bts = btab + (size_t)s0 * NF;
+        unsigned* ms = meta + (size_t)s0 * meta_words(n);
+        unsigned* rks = rank + (size_t)s0 * n;
+        if (Gs == 1) hipLaunchKernelGGL(kr_part<true>, dim3(1, Bs), dim3(RK_PT), (size_t)NF * 2, st, Ys, n, bts, ms, NF, lgBPO, mag, idxA, flag);
+        else hipLaunchKernelGGL(kr_part<false>, dim3(Gs, Bs), dim3(RK_PT), (size_t)NF * 2, st, Ys, n, bts, ms, NF, lgBPO, mag, idxA, flag);
+        hipLaunchKernelGGL(kr_bucket<RK_LGNSB>, dim3((unsigned)nbmax * (((unsigned)Bs + 7u) & ~7u)), dim3(RK_KT), 0, st, mag, idxA, n, lgn, ms, rks, Bs, flag, NF, lgBPO);
+    }
     hipLaunchKernelGGL(kr_finish, dim3(B), dim3(64), 0, st, meta, n, B, fg, S_e);
     WN_HIP(ctx, hipGetLastError());
     if (pending) {

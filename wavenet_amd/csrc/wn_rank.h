@@ -12,9 +12,9 @@
 //   3. kr_part   every non-zero magnitude, with its home index, goes to its bucket's range of a staging array
 //                (order inside the bucket: as it comes);
 //   4. kr_bucket one workgroup per bucket: a counting sort in LDS over 4096 sub-bins that split the bucket's
-//                own magnitude range linearly, exact (magnitude, index) comparison inside a sub-bin, the rank
-//                written to the coefficient's home position, and the bucket's share of the two Gini sums from
-//                the magnitudes in sorted order;
+//                own magnitude range linearly, exact order inside a sub-bin from 64-bit keys (what is left of the
+//                magnitude, then the home index), the rank written to the coefficient's home position, and the
+//                bucket's share of the two Gini sums from the magnitudes in sorted order;
 //   5. kr_finish adds the buckets' shares per example: lane l of a wave takes buckets l, l + 64, ... in order, the lanes are
 //                combined by a butterfly.
 // Exact zeros are left out (they rank first and need no rank of their own).  Every rank is decided by exact
@@ -40,7 +40,7 @@ constexpr int RK_PT = 512;       // threads of kr_hist / kr_part
 constexpr int RK_BT = 1024;      // threads of kr_scan
 constexpr int RK_KT = 512;       // threads of kr_bucket
 constexpr int RK_KE = 8;         // magnitudes (and sub-bins) per thread of kr_bucket
-constexpr int RK_NSB = 4096;     // sub-bins of a bucket
+constexpr int RK_LGNSB = 12;     // log2 of the sub-bins of a bucket
 constexpr int RK_NBMAX = 1024;   // buckets per example at most: examples of up to 2^21 coefficients
 constexpr int RK_LGN_MAX = 21;
 
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(RK_PT) void kr_part(const double* __restrict__ Y, s
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const size_t i = first + 2 * (size_t)(k * RK_PT + tid);
-        nx[k] = (i < last) ? *reinterpret_cast<const double2*>(src + i) : make_double2(0.0, 0.0);
+        nx[k] = *reinterpret_cast<const double2*>(src + (i < last ? i : last - 2));   // (beyond the end: a valid address, the value is dropped when used)
     }
     for (size_t i0 = first; i0 < last; i0 += RK_TILE) {
         unsigned long long bits[4];
@@ -264,14 +264,14 @@ __global__ __launch_bounds__(RK_PT) void kr_part(const double* __restrict__ Y, s
         unsigned o[4];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const double2 v = nx[k];
+            const double2 v = (i0 + 2 * (size_t)(k * RK_PT + tid) < last) ? nx[k] : make_double2(0.0, 0.0);
             bits[2 * k] = (unsigned long long)__double_as_longlong(v.x) & 0x7FFFFFFFFFFFFFFFull;
             bits[2 * k + 1] = (unsigned long long)__double_as_longlong(v.y) & 0x7FFFFFFFFFFFFFFFull;
             // (v != 0) rather than (bits != 0): the same test as everywhere else, true for NaN
             if (!(v.x != 0.0)) bits[2 * k] = 0;
             if (!(v.y != 0.0)) bits[2 * k + 1] = 0;
             const size_t i = i0 + RK_TILE + 2 * (size_t)(k * RK_PT + tid);      // the next step's coefficients, on their way early
-            nx[k] = (i < last) ? *reinterpret_cast<const double2*>(src + i) : make_double2(0.0, 0.0);
+            nx[k] = *reinterpret_cast<const double2*>(src + (i < last ? i : last - 2));
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -312,96 +312,130 @@ __global__ __launch_bounds__(RK_PT) void kr_part(const double* __restrict__ Y, s
             }
         }
         lds_barrier();
-        for (unsigned p = tid; p < total; p += RK_PT) {
-            const unsigned d = dstL[p];
-            mo[d] = bitsL[p];
-            io[d] = idxL[p];
+        // a fixed number of stores per step (lanes beyond the step's non-zeros repeat its last element), so that the wait for
+        // the prefetched coefficients can leave the stores in flight
+        {
+            // (a step without non-zeros: the example then has at least RK_TILE zeros, so the last RK_TILE entries of its
+            // staging arrays are never read and can take the stores)
+#pragma unroll
+            for (int k = 0; k < RK_TILE / RK_PT; k++) {
+                const unsigned p = total ? min((unsigned)(tid + k * RK_PT), total - 1u) : 0u;
+                const unsigned d = total ? dstL[p] : (unsigned)n - 1u - (unsigned)tid;
+                mo[d] = bitsL[p];
+                io[d] = idxL[p];
+            }
         }
     }
 }
 
-// LDS of kr_bucket.  64.6 KB: two workgroups of 512 threads per CU (the kernel wants about 100 registers per
-// thread), so that one's loads and barriers hide behind the other's LDS work.
+// ---- kr_bucket ------------------------------------------------------------------------------------------------
+// Inclusive prefix sum over the 64 lanes of a wave by DPP row shifts and row broadcasts (no LDS traffic); every
+// lane of the wave must be active.
+__device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+#ifndef RK_B2_WAVES
+#define RK_B2_WAVES 6     // waves per SIMD kr_bucket is compiled for (6: 80 registers, three workgroups per CU)
+#endif
+// LDS of kr_bucket: keys and sub-bin counters only (48.3 KB at 4096 sub-bins: three workgroups per CU).
+template <int LGNSB>
 struct BucketLds {
     unsigned long long keyB[RK_CAP];
-    unsigned idxB[RK_CAP], st[RK_NSB + 4];
-    unsigned wsum[RK_KT / 64 + 1];
+    unsigned st[(1 << LGNSB) + 4];
+    unsigned wsum[RK_KT / 64];
     unsigned long long wlo[RK_KT / 64], whi[RK_KT / 64];
     double red[2 * (RK_KT / 64)];
 };
 
-// The sorting part of kr_bucket.  Sub-bin = the leading 12 bits of (magnitude - lo).  PACKED: what is left of the
-// magnitude below those bits, with the home index behind it, is ONE 64-bit key (both fit, except for a bucket that
-// spans dozens of octaves: the lowest one), the order inside a sub-bin is one comparison per pair, and from the keys
-// on a magnitude is carried as its key only (bits = lo + (sub-bin << sh) + key's upper part).  Otherwise magnitudes
-// and indices are kept side by side.  Returns through `bits` the magnitudes' bit patterns and through `o` their
-// ranks inside the bucket; writes the ranks home.
-template <bool PACKED>
-__device__ __forceinline__ void bucket_sort(BucketLds& L, unsigned long long (&bits)[RK_KE], unsigned (&id)[RK_KE], unsigned (&o)[RK_KE],
-                                            unsigned count, unsigned long long lo, int sh, int lgn, unsigned* rk, unsigned rank0) {
+// The ranks inside the sub-bins.  A magnitude's key is what is left of it below its sub-bin bits with a payload
+// behind it: the home index where both fit in 64 bits, else (SLOTS) the magnitude's slot in the bucket, which always
+// fits; with slots, equal magnitudes are ordered by the home indices read from memory.
+template <int LGNSB, bool SLOTS>
+__device__ __forceinline__ void bucket_ranks(BucketLds<LGNSB>& L, unsigned long long (&key)[RK_KE], const unsigned (&sb)[RK_KE],
+                                              unsigned (&o)[RK_KE], unsigned count, int PB, const unsigned* __restrict__ ii,
+                                              unsigned* rk, unsigned rank0) {
     const int tid = threadIdx.x;
-    const unsigned long long remmask = sh ? ((1ull << sh) - 1ull) : 0ull;
-    const unsigned idmask = (1u << lgn) - 1u;          // lgn <= RK_LGN_MAX
-    unsigned sb[RK_KE];
+    const unsigned pmask = (1u << PB) - 1u;
+    if constexpr (!SLOTS) {
+        // Keys are unique, so the rank inside a sub-bin is the number of smaller keys in it.  The first RK_W keys of
+        // every sub-bin are read at once, without a branch (what lies beyond the sub-bin's end is read and not
+        // counted): sub-bins hold 3/4 of a key on average, and a loop over their members would wait for LDS once
+        // per member.  Only sub-bins of more than RK_W keys go through a loop for the rest.
+        constexpr int RK_W = 4;
+        constexpr int RK_G = 2;                  // keys whose sub-bins are read together
 #pragma unroll
-    for (int k = 0; k < RK_KE; k++) {
-        const unsigned long long rel = bits[k] - lo;
-        sb[k] = (unsigned)(rel >> sh);
-        if (PACKED) bits[k] = ((rel & remmask) << lgn) | id[k];
-        o[k] = 0;
-        if (tid + k * RK_KT < count) o[k] = atomicAdd(&L.st[sb[k]], 1u);
-    }
-    lds_barrier();
-    {   // counts -> exclusive prefix sums, in place: RK_KE consecutive sub-bins per thread
-        unsigned c4[RK_KE], s = 0;
+        for (int h = 0; h < RK_KE; h += RK_G) {
+            unsigned g0[RK_G], sz[RK_G];
+            unsigned long long m[RK_G][RK_W];
 #pragma unroll
-        for (int k = 0; k < RK_KE; k++) { c4[k] = L.st[RK_KE * tid + k]; s += c4[k]; }
-        unsigned run = block_exclusive_scan<RK_KT>(s, L.wsum, nullptr);
+            for (int k = 0; k < RK_G; k++) {
+                g0[k] = L.st[sb[h + k]];
+                sz[k] = L.st[sb[h + k] + 1] - g0[k];
+            }
 #pragma unroll
-        for (int k = 0; k < RK_KE; k++) { L.st[RK_KE * tid + k] = run; run += c4[k]; }
-        if (tid == RK_KT - 1) L.st[RK_NSB] = run;
-    }
-    lds_barrier();
+            for (int k = 0; k < RK_G; k++) {
 #pragma unroll
-    for (int k = 0; k < RK_KE; k++) {
-        if (tid + k * RK_KT < count) {
-            const unsigned pos = L.st[sb[k]] + o[k];
-            L.keyB[pos] = bits[k];
-            if (!PACKED) L.idxB[pos] = id[k];
+                for (int w = 0; w < RK_W; w++) m[k][w] = L.keyB[g0[k] + w];    // (at most RK_W - 1 entries beyond the keys: the counters follow)
+            }
+#pragma unroll
+            for (int k = 0; k < RK_G; k++) {
+                unsigned r = g0[k];
+#pragma unroll
+                for (int w = 0; w < RK_W; w++) r += ((unsigned)w < sz[k] && m[k][w] < key[h + k]) ? 1u : 0u;
+                if (sz[k] > (unsigned)RK_W) {
+                    for (unsigned q = g0[k] + RK_W; q < g0[k] + sz[k]; q++) r += (L.keyB[q] < key[h + k]) ? 1u : 0u;
+                }
+                if (tid + (h + k) * RK_KT < count) rk[(unsigned)key[h + k] & pmask] = rank0 + r;
+                o[h + k] = r;
+            }
         }
-    }
-    lds_barrier();
+    } else {
 #pragma unroll
-    for (int k = 0; k < RK_KE; k++) {
-        if (tid + k * RK_KT < count) {
-            const unsigned g0 = L.st[sb[k]], g1 = L.st[sb[k] + 1];
-            unsigned r = g0;
-            if (g1 - g0 > 1) {
-                if (PACKED) {
-                    for (unsigned q = g0; q < g1; q++) r += (L.keyB[q] < bits[k]) ? 1u : 0u;
-                } else {
+        for (int k = 0; k < RK_KE; k++) {
+            const unsigned j = tid + k * RK_KT;
+            if (j < count) {
+                const unsigned g0 = L.st[sb[k]], g1 = L.st[sb[k] + 1];
+                unsigned r = g0;
+                if (g1 - g0 > 1) {
+                    const unsigned long long mine = key[k] >> PB;
+                    unsigned myid = 0xFFFFFFFFu;
                     for (unsigned q = g0; q < g1; q++) {
                         const unsigned long long kq = L.keyB[q];
-                        r += (kq < bits[k] || (kq == bits[k] && L.idxB[q] < id[k])) ? 1u : 0u;
+                        if ((kq >> PB) != mine) r += ((kq >> PB) < mine) ? 1u : 0u;
+                        else if (kq != key[k]) {      // an equal magnitude in another slot: the home indices decide
+                            if (myid == 0xFFFFFFFFu) myid = ii[j];
+                            r += (ii[(unsigned)kq & pmask] < myid) ? 1u : 0u;
+                        }
                     }
                 }
+                rk[ii[j]] = rank0 + r;
+                o[k] = r;
             }
-            const unsigned home = PACKED ? ((unsigned)bits[k] & idmask) : id[k];
-            rk[home] = rank0 + r;
-            o[k] = r;
-            if (PACKED) bits[k] = lo + ((unsigned long long)sb[k] << sh) + (bits[k] >> lgn);
         }
     }
 }
 
-// One bucket: exact ranks home, the bucket's share of f = sum (2 rank - n - 1) |c| and of sum |c|.
+// One bucket: exact ranks home, the bucket's share of f = sum (2 rank - n - 1) |c| and of sum |c|.  A counting sort in
+// LDS over the sub-bins (the leading LGNSB bits of magnitude - bucket minimum), the workgroup-wide prefix sum of the
+// counts by DPP scans and one hand-over, exact order inside a sub-bin from the keys, then the magnitudes once more in
+// sorted order for the two sums (a fixed order of addition, whatever order the bucket arrived in).  lgn = log2 n.
 // 1D grid of nbmax * (examples rounded up to 8) workgroups: consecutive workgroups go to consecutive XCDs, so
 // workgroup L works on example (L / 8 / nbmax) * 8 + L % 8 -- all buckets of an example share one XCD, whose L2
 // then collects the example's scattered ranks into whole lines.
-__global__ __launch_bounds__(RK_KT, 4) void kr_bucket(const unsigned long long* __restrict__ mag, const unsigned* __restrict__ idx, size_t n,
-                                                      unsigned* meta_all, unsigned* rank, int B, const unsigned* flag, int NF, int lgBPO) {
-    __shared__ BucketLds L;
-    static_assert(RK_NSB == RK_KE * RK_KT && RK_CAP == RK_KE * RK_KT, "RK_KE sub-bins and RK_KE magnitudes per thread");
+template <int LGNSB>
+__global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned long long* __restrict__ mag, const unsigned* __restrict__ idx, size_t n, int lgn,
+                                                    unsigned* meta_all, unsigned* rank, int B, const unsigned* flag, int NF, int lgBPO) {
+    constexpr int NSB = 1 << LGNSB;
+    constexpr int SPT = NSB / RK_KT;            // sub-bins per thread in the prefix sum
+    static_assert(SPT % 4 == 0 && RK_CAP == RK_KE * RK_KT, "whole 16-byte pieces of counters per thread; RK_KE magnitudes per thread");
+    __shared__ __attribute__((aligned(16))) BucketLds<LGNSB> L;
     const int nbmax = nbmax_for(n);
     const int slot = blockIdx.x >> 3;
     const int e = (slot / nbmax) * 8 + (blockIdx.x & 7), b = slot % nbmax;
@@ -415,72 +449,118 @@ __global__ __launch_bounds__(RK_KT, 4) void kr_bucket(const unsigned long long* 
     const unsigned zeros = (unsigned)n - nz;
     const unsigned long long* mi = mag + (size_t)e * n + s0;
     const unsigned* ii = idx + (size_t)e * n + s0;
-    unsigned long long bits[RK_KE];
-    unsigned id[RK_KE], o[RK_KE];
+    unsigned long long key[RK_KE];
+    unsigned id[RK_KE], o[RK_KE], sb[RK_KE];
+#pragma unroll
+    for (int k = 0; k < RK_KE; k++) {
+        const unsigned j = min((unsigned)(tid + k * RK_KT), count - 1u);   // (slots beyond the bucket repeat its last magnitude and are left out below)
+        key[k] = mi[j];
+        id[k] = ii[j];
+    }
+    {
+        uint4* z = reinterpret_cast<uint4*>(L.st) + tid * (SPT / 4);
+#pragma unroll
+        for (int q = 0; q < SPT / 4; q++) z[q] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < 4) L.st[NSB + tid] = 0;
+    }
+    // the range of the bucket's magnitudes, from the bins it is made of
+    const unsigned f0 = meta_binfirst(meta, nbmax)[b], fnext = meta_binfirst(meta, nbmax)[b + 1];
+    unsigned long long lo, hi;
+    bin_range(f0, (fnext > f0 ? fnext : (unsigned)NF) - 1u, meta[2], meta[3], lgBPO, NF, &lo, &hi);
+    if (f0 == 0) {
+        // the lowest bin reaches down to zero: the bucket's own smallest and largest magnitude instead
+        lo = ~0ull;
+        hi = 0;
+#pragma unroll
+        for (int k = 0; k < RK_KE; k++) {      // (the repeats beyond the bucket change nothing)
+            lo = key[k] < lo ? key[k] : lo;
+            hi = key[k] > hi ? key[k] : hi;
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            const unsigned long long l2 = (unsigned long long)__shfl_xor((long long)lo, s, 64), h2 = (unsigned long long)__shfl_xor((long long)hi, s, 64);
+            lo = l2 < lo ? l2 : lo;
+            hi = h2 > hi ? h2 : hi;
+        }
+        if (lane == 0) { L.wlo[wave] = lo; L.whi[wave] = hi; }
+    }
+    lds_barrier();         // counters zero, the waves' ranges in place
+    if (f0 == 0) {
+#pragma unroll
+        for (int w = 0; w < RK_KT / 64; w++) {
+            lo = L.wlo[w] < lo ? L.wlo[w] : lo;
+            hi = L.whi[w] > hi ? L.whi[w] : hi;
+        }
+    }
+    const unsigned long long span = hi - lo;
+    const int sh = (span >> LGNSB) ? (64 - __builtin_clzll(span) - LGNSB) : 0;   // (span >> sh) < NSB
+    const bool slots = sh + lgn > 64;            // the home index does not fit behind what is left of a magnitude
+    const int PB = slots ? 12 : lgn;
+    static_assert(RK_CAP <= 4096, "a slot number takes 12 bits");
+    const unsigned long long remmask = sh ? ((1ull << sh) - 1ull) : 0ull;
 #pragma unroll
     for (int k = 0; k < RK_KE; k++) {
         const unsigned j = tid + k * RK_KT;
-        bits[k] = 0;
-        id[k] = 0;
-        if (j < count) {
-            bits[k] = mi[j];
-            id[k] = ii[j];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < RK_KE; k++) L.st[RK_KE * tid + k] = 0;   // counts first, their prefix sums later
-    // the range of the bucket's magnitudes, from the bins it is made of
-    unsigned long long lo, hi;
-    {
-        const unsigned f0 = meta_binfirst(meta, nbmax)[b], fnext = meta_binfirst(meta, nbmax)[b + 1];
-        bin_range(f0, (fnext > f0 ? fnext : (unsigned)NF) - 1u, meta[2], meta[3], lgBPO, NF, &lo, &hi);
-        if (f0 == 0) {
-            // the lowest bin reaches down to zero: take the bucket's own smallest and largest magnitude instead, or a few
-            // stragglers far below the rest would leave everything else in a handful of sub-bins
-            lo = ~0ull;
-            hi = 0;
-#pragma unroll
-            for (int k = 0; k < RK_KE; k++) {
-                if (tid + k * RK_KT < count) {
-                    lo = bits[k] < lo ? bits[k] : lo;
-                    hi = bits[k] > hi ? bits[k] : hi;
-                }
-            }
-#pragma unroll
-            for (int s = 32; s > 0; s >>= 1) {
-                const unsigned long long l2 = (unsigned long long)__shfl_xor((long long)lo, s, 64), h2 = (unsigned long long)__shfl_xor((long long)hi, s, 64);
-                lo = l2 < lo ? l2 : lo;
-                hi = h2 > hi ? h2 : hi;
-            }
-            if (lane == 0) { L.wlo[wave] = lo; L.whi[wave] = hi; }
-            lds_barrier();
-#pragma unroll
-            for (int w = 0; w < RK_KT / 64; w++) {
-                lo = L.wlo[w] < lo ? L.wlo[w] : lo;
-                hi = L.whi[w] > hi ? L.whi[w] : hi;
-            }
-        }
+        const unsigned long long rel = key[k] - lo;
+        sb[k] = (unsigned)(rel >> sh);
+        key[k] = ((rel & remmask) << PB) | (slots ? j : id[k]);
+        o[k] = 0;
+        if (j < count) o[k] = atomicAdd(&L.st[sb[k]], 1u);
     }
     lds_barrier();
-    int lgn = 0;
-    while (((size_t)1 << lgn) < n) lgn++;
-    const unsigned long long span = hi - lo;
-    const int sh = (span >> 12) ? (64 - __builtin_clzll(span) - 12) : 0;   // (span >> sh) < RK_NSB = 4096
+    {   // counts -> exclusive prefix sums, in place: SPT consecutive sub-bins per thread
+        unsigned c[SPT], s = 0;
+        uint4* p4 = reinterpret_cast<uint4*>(L.st) + tid * (SPT / 4);
+#pragma unroll
+        for (int q = 0; q < SPT / 4; q++) {
+            const uint4 t = p4[q];
+            c[4 * q] = t.x; c[4 * q + 1] = t.y; c[4 * q + 2] = t.z; c[4 * q + 3] = t.w;
+            s += t.x + t.y + t.z + t.w;
+        }
+        const unsigned incl = wave_inclusive_scan(s);
+        if (lane == 63) L.wsum[wave] = incl;
+        lds_barrier();
+        unsigned run = incl - s;
+#pragma unroll
+        for (int w = 0; w < RK_KT / 64 - 1; w++) run += (w < wave) ? L.wsum[w] : 0u;
+#pragma unroll
+        for (int q = 0; q < SPT / 4; q++) {
+            uint4 t;
+            t.x = run; run += c[4 * q];
+            t.y = run; run += c[4 * q + 1];
+            t.z = run; run += c[4 * q + 2];
+            t.w = run; run += c[4 * q + 3];
+            p4[q] = t;
+        }
+        if (tid == RK_KT - 1) L.st[NSB] = run;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < RK_KE; k++) {
+        if (tid + k * RK_KT < count) L.keyB[L.st[sb[k]] + o[k]] = key[k];
+    }
+    lds_barrier();
     unsigned* rk = rank + (size_t)e * n;
-    if (sh + lgn <= 64) bucket_sort<true>(L, bits, id, o, count, lo, sh, lgn, rk, zeros + s0 + 1u);
-    else bucket_sort<false>(L, bits, id, o, count, lo, sh, lgn, rk, zeros + s0 + 1u);
+    const unsigned rank0 = zeros + s0 + 1u;
+    if (!slots) bucket_ranks<LGNSB, false>(L, key, sb, o, count, PB, ii, rk, rank0);
+    else bucket_ranks<LGNSB, true>(L, key, sb, o, count, PB, ii, rk, rank0);
     lds_barrier();       // every comparison has read its keys: the array now takes the magnitudes in sorted order
     unsigned long long* magS = L.keyB;
 #pragma unroll
     for (int k = 0; k < RK_KE; k++) {
-        if (tid + k * RK_KT < count) magS[o[k]] = bits[k];
+        if (tid + k * RK_KT < count) magS[o[k]] = lo + ((unsigned long long)sb[k] << sh) + (key[k] >> PB);
     }
     lds_barrier();
     double f = 0, a = 0;
-    for (unsigned r = tid; r < count; r += RK_KT) {
-        const double av = __longlong_as_double((long long)magS[r]);
-        f = __builtin_fma(2.0 * (double)(zeros + s0 + r + 1u) - (double)n - 1.0, av, f);
-        a += av;
+    const double w0 = 2.0 * (double)rank0 - (double)n - 1.0;     // weight of the bucket's smallest magnitude (exact: integers below 2^53)
+#pragma unroll
+    for (int k = 0; k < RK_KE; k++) {
+        const unsigned r = tid + k * RK_KT;
+        if (r < count) {
+            const double av = __longlong_as_double((long long)magS[r]);
+            f = __builtin_fma(w0 + 2.0 * (double)r, av, f);
+            a += av;
+        }
     }
     f = wave_sum(f);
     a = wave_sum(a);
@@ -488,6 +568,7 @@ __global__ __launch_bounds__(RK_KT, 4) void kr_bucket(const unsigned long long* 
     lds_barrier();
     if (tid < 2) {
         double t = 0;
+#pragma unroll
         for (int w = 0; w < RK_KT / 64; w++) t += L.red[tid * (RK_KT / 64) + w];
         meta_bpart(meta, nbmax)[2 * b + tid] = t;
     }

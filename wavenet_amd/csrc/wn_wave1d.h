@@ -31,9 +31,29 @@ __device__ __forceinline__ double w1d_lane(double v, int src) {
     const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
-// v of lane (lane - D) mod 64
+// The wave rotated by one lane: lane i receives lane i - 1 (ror) or lane i + 1 (rol), modulo 64.  A DPP move in the
+// vector pipeline: no LDS instruction, unlike ds_bpermute, and the periodic boundary comes with it.  Every lane of
+// the wave must be active.
+__device__ __forceinline__ double w1d_ror1(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x13C, 0xf, 0xf, false);   // wave_ror:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x13C, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double w1d_rol1(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x134, 0xf, 0xf, false);   // wave_rol:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x134, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// v of lane (lane - D) mod 64: neighbours at distance 1 and 2 by rotations, the others through ds_bpermute
 template <int D>
 __device__ __forceinline__ double w1d_from(double v, int lane) {
+#ifndef WN_NO_DPP_ROTATE
+    if constexpr (D == 1) return w1d_ror1(v);
+    else if constexpr (D == -1) return w1d_rol1(v);
+    else if constexpr (D == 2) return w1d_ror1(w1d_ror1(v));
+    else if constexpr (D == -2) return w1d_rol1(w1d_rol1(v));
+    else
+#endif
     return w1d_lane(v, lane + ((64 - D) & 63));
 }
 
