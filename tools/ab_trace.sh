@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 for so in $ROOT/wavenet_amd/lib/exp/*.so; do
   name=$(basename $so .so)
   rm -rf /tmp/ab_$name
-  WAVENET_HIP_LIBRARY=$so timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_$name -o r -- python $ROOT/bench.py --workload $WORKLOAD --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline ${EXTRA:-} > $OUT/$name.json 2> $OUT/$name.err || { echo "$name FAILED"; tail -5 $OUT/$name.err; exit 1; }
+  WAVENET_HIP_LIBRARY=$so timeout -k 10 90 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_$name -o r -- python $ROOT/bench.py --workload $WORKLOAD --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline ${EXTRA:-} > $OUT/$name.json 2> $OUT/$name.err || { echo "$name FAILED"; tail -5 $OUT/$name.err; exit 1; }
   python3 - "$(find /tmp/ab_$name -name '*kernel_stats.csv' | head -1)" "$name" "$PATTERN" "$OUT/$name.json" <<'PY' | tee -a $OUT/summary.txt
 import csv, json, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))

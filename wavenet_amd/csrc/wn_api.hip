@@ -280,6 +280,7 @@ int wn_create(int device, wn_context** out) {
     if (const char* w = getenv("WAVENET_HIP_WAVE64")) ctx->wave64 = (w[0] != '0');
     if (const char* w = getenv("WAVENET_HIP_EXACT_SORT")) ctx->exact_sort = (w[0] == '1');
     if (const char* w = getenv("WAVENET_HIP_RANK")) ctx->bucket_rank = (strcmp(w, "radix") != 0);
+    if (const char* w = getenv("WAVENET_HIP_RANK_KEYS")) ctx->rank_packed = (strcmp(w, "12") != 0);
     if (const char* w = getenv("WAVENET_HIP_RANK_SUB")) ctx->rank_sub = std::max(0, atoi(w));
     if (const char* w = getenv("WAVENET_HIP_CHUNK")) ctx->chunk_cap = std::max(0, atoi(w));
     if (rc == WN_OK) alloc((void**)&ctx->dfilt, sizeof(wn::FilterDev));

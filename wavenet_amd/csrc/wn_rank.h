@@ -43,6 +43,12 @@ constexpr int RK_KE = 8;         // magnitudes (and sub-bins) per thread of kr_b
 constexpr int RK_LGNSB = 12;     // log2 of the sub-bins of a bucket
 constexpr int RK_NBMAX = 1024;   // buckets per example at most: examples of up to 2^21 coefficients
 constexpr int RK_LGN_MAX = 21;
+#ifndef RK_IB_BITS
+#define RK_IB_BITS 13
+#endif
+constexpr int RK_IB = RK_IB_BITS;                           // home index bits inside a packed staging key: the position within a region of the example
+constexpr int RK_REGION = 1 << RK_IB;                       // consecutive home positions that share the rest of their index
+constexpr int RK_STEPS_MAX = (1 << RK_LGN_MAX) >> RK_IB;    // regions per example at most
 
 // Workgroup barrier for hand-overs through LDS only: waits for this wave's LDS operations, not for its global
 // loads and stores (__syncthreads() also drains those, which would put the memory latency of every prefetch and
@@ -59,6 +65,8 @@ __host__ __device__ inline size_t meta_words(size_t n) {
 }
 __device__ __forceinline__ unsigned* meta_bstart(unsigned* m) { return m + 4; }
 __device__ __forceinline__ unsigned* meta_binfirst(unsigned* m, int nbmax) { return m + 4 + nbmax + 1; }
+__device__ __forceinline__ const unsigned* meta_bstart(const unsigned* m) { return m + 4; }
+__device__ __forceinline__ const unsigned* meta_binfirst(const unsigned* m, int nbmax) { return m + 4 + nbmax + 1; }
 __device__ __forceinline__ unsigned* meta_cursor(unsigned* m, int nbmax) { return m + 4 + 2 * (nbmax + 1); }
 __device__ __forceinline__ double* meta_bpart(unsigned* m, int nbmax) {
     return reinterpret_cast<double*>(m + ((4 + 2 * (nbmax + 1) + nbmax + 1) & ~1));
@@ -257,6 +265,10 @@ __global__ __launch_bounds__(RK_PT) void kr_part(const double* __restrict__ Y, s
     for (int k = 0; k < 2; k++) {
         const size_t i = first + 2 * (size_t)(k * RK_PT + tid);
         nx[k] = *reinterpret_cast<const double2*>(src + (i < last ? i : last - 2));   // (beyond the end: a valid address, the value is dropped when used)
+        // Used here already, on purpose: the first loads are then complete when the loop is entered, and the compiler's
+        // wait for the prefetched coefficients inside the loop can be "all but the eight stores behind them" on every
+        // path -- with loads still pending on the entry path it falls back to waiting for everything, stores included.
+        if (!(i < last)) nx[k] = make_double2(0.0, 0.0);
     }
     for (size_t i0 = first; i0 < last; i0 += RK_TILE) {
         unsigned long long bits[4];
@@ -328,6 +340,167 @@ __global__ __launch_bounds__(RK_PT) void kr_part(const double* __restrict__ Y, s
     }
 }
 
+// ---- packed staging: one 8-byte key per magnitude --------------------------------------------------------------
+// kr_part above writes 12 bytes per magnitude into two arrays.  A bucket's magnitudes lie within an octave or two of
+// its lower bound, so (magnitude - lower bound) takes at most 53 bits, and the 11 bits that are left hold the home
+// index modulo RK_TILE.  The rest of the index comes from WHERE a key sits in its bucket's range: a workgroup takes
+// the example's coefficients step by step (RK_TILE consecutive home positions per step) and appends to every bucket
+// what the step holds for it, so the keys of step s occupy the positions [snap[s][b], snap[s + 1][b]) of bucket b.
+// kr_part8 leaves those cursor snapshots (16-bit offsets from the bucket's start: a bucket holds at most RK_CAP keys)
+// and kr_bucket recovers home index = (step << RK_IB) | low bits by a search over its bucket's column of them.  A bucket
+// wider than 2^53 bit patterns (the lowest one, which reaches down to zero; sparse tails) keeps whatever fits of its
+// magnitudes; kr_bucket reads such a bucket's exact magnitudes back from the coefficients at the home positions.
+// With several workgroups per example each one's cursors start where kr_count says the workgroups before it end, so
+// the placement does not depend on the order in which workgroups run.
+
+__host__ __device__ inline int nbmax_even(size_t n) { return (nbmax_for(n) + 1) & ~1; }
+
+// precnt[(e * G + g) * nbmax_even + b] = number of non-zero coefficients of workgroup g's share of example e that go to
+// bucket b.  grid (G, B), RK_PT threads, NF * 2 bytes of dynamic LDS.  Only needed for G > 1.
+__global__ __launch_bounds__(RK_PT) void kr_count(const double* __restrict__ Y, size_t n, const unsigned short* __restrict__ btab,
+                                                  const unsigned* __restrict__ meta_all, int NF, int lgBPO, unsigned* precnt,
+                                                  const unsigned* flag) {
+    extern __shared__ unsigned short rk_bt[];
+    __shared__ unsigned cnt[RK_NBMAX];
+    if (*flag) return;
+    const int e = blockIdx.y, tid = threadIdx.x;
+    const int nbe = nbmax_even(n);
+    const unsigned* meta = meta_all + (size_t)e * meta_words(n);
+    const unsigned Lmax = meta[2];
+    for (int f = tid; f < NF; f += RK_PT) rk_bt[f] = btab[(size_t)e * NF + f];
+    for (int b = tid; b < RK_NBMAX; b += RK_PT) cnt[b] = 0;
+    lds_barrier();
+    const size_t per = n / gridDim.x;
+    const double* src = Y + (size_t)e * n + (size_t)blockIdx.x * per;
+    for (size_t i0 = 0; i0 < per; i0 += 8 * RK_PT) {
+        double2 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const size_t i = i0 + 2 * (size_t)(k * RK_PT + tid);
+            v[k] = *reinterpret_cast<const double2*>(src + (i < per ? i : per - 2));
+            if (!(i < per)) v[k] = make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (v[k].x != 0.0) atomicAdd(&cnt[rk_bt[fine_bin((unsigned)__double2hiint(v[k].x) & 0x7FFFFFFFu, Lmax, lgBPO, NF)]], 1u);
+            if (v[k].y != 0.0) atomicAdd(&cnt[rk_bt[fine_bin((unsigned)__double2hiint(v[k].y) & 0x7FFFFFFFu, Lmax, lgBPO, NF)]], 1u);
+        }
+    }
+    __syncthreads();
+    unsigned* out = precnt + ((size_t)e * gridDim.x + blockIdx.x) * nbe;
+    for (int b = tid; b < nbe; b += RK_PT) out[b] = cnt[b];
+}
+
+// Packed keys of the non-zero magnitudes into their buckets' ranges of keys (per example n entries, bucket b at
+// [bstart[b], bstart[b+1])), and the cursor snapshots snap[(e * steps + step) * nbmax_even + b].  Steps as in kr_part.
+// grid (G, B), RK_PT threads; dynamic LDS: btab, NF * 2 bytes.  precnt: kr_count's counts (G > 1), else null.
+__global__ __launch_bounds__(RK_PT) void kr_part8(const double* __restrict__ Y, size_t n, const unsigned short* __restrict__ btab,
+                                                  const unsigned* __restrict__ meta_all, int NF, int lgBPO, unsigned long long* keys,
+                                                  unsigned short* snap, const unsigned* __restrict__ precnt, const unsigned* flag) {
+    static_assert(RK_TILE == 4 * RK_PT && RK_NBMAX == 2 * RK_PT && RK_REGION % RK_TILE == 0, "four coefficients and two buckets per thread; whole steps per region");
+    extern __shared__ unsigned short rk_bt[];
+    __shared__ unsigned cnt[RK_NBMAX], gb[RK_NBMAX], bst[RK_NBMAX], bs0[RK_NBMAX], lo32[RK_NBMAX];
+    __shared__ unsigned short lst[RK_NBMAX];     // 79 KB with the rest: two workgroups per CU
+    __shared__ unsigned long long keyL[RK_TILE];
+    __shared__ unsigned dstL[RK_TILE];
+    __shared__ unsigned wsum[RK_PT / 64 + 1];
+    if (*flag) return;     // some bucket overflows: the caller will rank another way
+    const int e = blockIdx.y, tid = threadIdx.x;
+    const int nbmax = nbmax_for(n), nbe = nbmax_even(n);
+    const unsigned* meta = meta_all + (size_t)e * meta_words(n);
+    const unsigned Lmax = meta[2], kmx = meta[3];
+    const int nb = (int)meta[1];
+    for (int f = tid; f < NF; f += RK_PT) rk_bt[f] = btab[(size_t)e * NF + f];
+    for (int b = tid; b < RK_NBMAX; b += RK_PT) {
+        cnt[b] = 0;
+        unsigned start = (b < nbmax) ? meta_bstart(meta)[b] : 0u, low = 0;
+        bs0[b] = start;
+        if (b < nb) {
+            const unsigned f0 = meta_binfirst(meta, nbmax)[b], fnext = meta_binfirst(meta, nbmax)[b + 1];
+            unsigned long long lo, hi;
+            bin_range(f0, (fnext > f0 ? fnext : (unsigned)NF) - 1u, Lmax, kmx, lgBPO, NF, &lo, &hi);
+            low = (unsigned)(lo >> 32);              // (the lower bound of a range of bins has no low word)
+            if (precnt) {
+                for (int g = 0; g < (int)blockIdx.x; g++) start += precnt[((size_t)e * gridDim.x + g) * nbe + b];
+            }
+        }
+        bst[b] = start;
+        lo32[b] = low;
+    }
+    lds_barrier();
+    const size_t per = n / gridDim.x, first = (size_t)blockIdx.x * per, last = first + per;
+    const double* src = Y + (size_t)e * n;
+    unsigned long long* ko = keys + (size_t)e * n;
+    unsigned* sn = reinterpret_cast<unsigned*>(snap + (size_t)e * (n / RK_REGION) * nbe);    // two buckets per word
+    double2 nx[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const size_t i = first + 2 * (size_t)(k * RK_PT + tid);
+        nx[k] = *reinterpret_cast<const double2*>(src + (i < last ? i : last - 2));
+        if (!(i < last)) nx[k] = make_double2(0.0, 0.0);       // (used here on purpose, see kr_part)
+    }
+    for (size_t i0 = first; i0 < last; i0 += RK_TILE) {
+        unsigned long long bits[4];
+        unsigned short bk[4];
+        unsigned o[4];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const double2 v = (i0 + 2 * (size_t)(k * RK_PT + tid) < last) ? nx[k] : make_double2(0.0, 0.0);
+            bits[2 * k] = (unsigned long long)__double_as_longlong(v.x) & 0x7FFFFFFFFFFFFFFFull;
+            bits[2 * k + 1] = (unsigned long long)__double_as_longlong(v.y) & 0x7FFFFFFFFFFFFFFFull;
+            if (!(v.x != 0.0)) bits[2 * k] = 0;
+            if (!(v.y != 0.0)) bits[2 * k + 1] = 0;
+            const size_t i = i0 + RK_TILE + 2 * (size_t)(k * RK_PT + tid);      // the next step's coefficients, on their way early
+            nx[k] = *reinterpret_cast<const double2*>(src + (i < last ? i : last - 2));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            bk[k] = 0;
+            o[k] = 0;
+            if (bits[k]) {
+                bk[k] = rk_bt[fine_bin((unsigned)(bits[k] >> 32), Lmax, lgBPO, NF)];
+                o[k] = atomicAdd(&cnt[bk[k]], 1u);
+            }
+        }
+        lds_barrier();
+        unsigned total;
+        {   // where each bucket's keys of this step start: in the LDS copy (lst) and in the bucket's range (gb); the cursors as they
+            // stand before the step are its snapshot
+            const unsigned c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
+            const unsigned run = block_exclusive_scan<RK_PT>(c0 + c1, wsum, &total);
+            lst[2 * tid] = (unsigned short)run;
+            lst[2 * tid + 1] = (unsigned short)(run + c0);
+            const unsigned p0 = bst[2 * tid], p1 = bst[2 * tid + 1];
+            if (2 * tid < nbe && (i0 & (size_t)(RK_REGION - 1)) == 0)      // the first step of a region
+                sn[(i0 >> RK_IB) * (size_t)(nbe / 2) + tid] = ((p0 - bs0[2 * tid]) & 0xFFFFu) | ((p1 - bs0[2 * tid + 1]) << 16);
+            gb[2 * tid] = p0;
+            gb[2 * tid + 1] = p1;
+            bst[2 * tid] = p0 + c0;
+            bst[2 * tid + 1] = p1 + c1;
+            cnt[2 * tid] = 0;
+            cnt[2 * tid + 1] = 0;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (bits[k]) {
+                const unsigned within = ((unsigned)i0 & (unsigned)(RK_REGION - 1)) + 2u * (unsigned)((k >> 1) * RK_PT + tid) + (unsigned)(k & 1);    // home index modulo RK_REGION
+                const unsigned lp = lst[bk[k]] + o[k];
+                keyL[lp] = ((bits[k] - ((unsigned long long)lo32[bk[k]] << 32)) << RK_IB) | within;
+                dstL[lp] = gb[bk[k]] + o[k];
+            }
+        }
+        lds_barrier();
+        // a fixed number of stores per step, as in kr_part
+#pragma unroll
+        for (int k = 0; k < RK_TILE / RK_PT; k++) {
+            const unsigned p = total ? min((unsigned)(tid + k * RK_PT), total - 1u) : 0u;
+            const unsigned d = total ? dstL[p] : (unsigned)n - 1u - (unsigned)tid;
+            ko[d] = keyL[p];
+        }
+    }
+}
+
 // ---- kr_bucket ------------------------------------------------------------------------------------------------
 // Inclusive prefix sum over the 64 lanes of a wave by DPP row shifts and row broadcasts (no LDS traffic); every
 // lane of the wave must be active.
@@ -349,6 +522,7 @@ template <int LGNSB>
 struct BucketLds {
     unsigned long long keyB[RK_CAP];
     unsigned st[(1 << LGNSB) + 4];
+    unsigned short col[RK_STEPS_MAX + 2];      // packed staging: the bucket's column of cursor snapshots, then its size
     unsigned wsum[RK_KT / 64];
     unsigned long long wlo[RK_KT / 64], whi[RK_KT / 64];
     double red[2 * (RK_KT / 64)];
@@ -357,10 +531,41 @@ struct BucketLds {
 // The ranks inside the sub-bins.  A magnitude's key is what is left of it below its sub-bin bits with a payload
 // behind it: the home index where both fit in 64 bits, else (SLOTS) the magnitude's slot in the bucket, which always
 // fits; with slots, equal magnitudes are ordered by the home indices read from memory.
-template <int LGNSB, bool SLOTS>
-__device__ __forceinline__ void bucket_ranks(BucketLds<LGNSB>& L, unsigned long long (&key)[RK_KE], const unsigned (&sb)[RK_KE],
-                                              unsigned (&o)[RK_KE], unsigned count, int PB, const unsigned* __restrict__ ii,
-                                              unsigned* rk, unsigned rank0) {
+// Home index of the magnitude in slot j of a bucket: from the index array, or (packed staging) from the slot's step,
+// found in the bucket's column of cursor snapshots, and the low bits of its key.
+template <bool PACKED8>
+struct BucketHomes {
+    const unsigned* ii;
+    const unsigned long long* mi;
+    const unsigned short* col;
+    int steps;
+    __device__ __forceinline__ unsigned step_of(unsigned j) const {
+        int lo = 0, hi = steps;                      // col[lo] <= j < col[hi] (col[steps] = size of the bucket)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (col[mid] <= j) lo = mid; else hi = mid;
+        }
+        return (unsigned)lo;
+    }
+    __device__ __forceinline__ unsigned operator()(unsigned j) const {
+        if constexpr (!PACKED8) return ii[j];
+        else return (step_of(j) << RK_IB) | ((unsigned)mi[j] & ((1u << RK_IB) - 1u));
+    }
+};
+
+// slot of the k-th magnitude of a thread: strided over the workgroup, or (packed staging) strided over the wave, so that
+// a wave's slots are 512 consecutive ones and a lane's step numbers can be followed from one slot to the next
+template <bool PACKED8>
+__device__ __forceinline__ unsigned bucket_slot(int tid, int k) {
+    if constexpr (!PACKED8) return (unsigned)(tid + k * RK_KT);
+    else return (unsigned)(((tid >> 6) * RK_KE + k) * 64 + (tid & 63));
+}
+
+// so[k]: sub-bin of the thread's k-th magnitude in the low half; its place inside the sub-bin comes in and its rank
+// inside the bucket goes out in the high half (both below RK_CAP).
+template <int LGNSB, bool SLOTS, bool PACKED8>
+__device__ __forceinline__ void bucket_ranks(BucketLds<LGNSB>& L, unsigned long long (&key)[RK_KE], unsigned (&so)[RK_KE],
+                                              unsigned count, int PB, const BucketHomes<PACKED8>& home, unsigned* rk, unsigned rank0) {
     const int tid = threadIdx.x;
     const unsigned pmask = (1u << PB) - 1u;
     if constexpr (!SLOTS) {
@@ -376,8 +581,8 @@ __device__ __forceinline__ void bucket_ranks(BucketLds<LGNSB>& L, unsigned long 
             unsigned long long m[RK_G][RK_W];
 #pragma unroll
             for (int k = 0; k < RK_G; k++) {
-                g0[k] = L.st[sb[h + k]];
-                sz[k] = L.st[sb[h + k] + 1] - g0[k];
+                g0[k] = L.st[so[h + k] & 0xFFFFu];
+                sz[k] = L.st[(so[h + k] & 0xFFFFu) + 1] - g0[k];
             }
 #pragma unroll
             for (int k = 0; k < RK_G; k++) {
@@ -389,19 +594,20 @@ __device__ __forceinline__ void bucket_ranks(BucketLds<LGNSB>& L, unsigned long 
                 unsigned r = g0[k];
 #pragma unroll
                 for (int w = 0; w < RK_W; w++) r += ((unsigned)w < sz[k] && m[k][w] < key[h + k]) ? 1u : 0u;
-                if (sz[k] > (unsigned)RK_W) {
+                const bool on = bucket_slot<PACKED8>(tid, h + k) < count;
+                if (on && sz[k] > (unsigned)RK_W) {
                     for (unsigned q = g0[k] + RK_W; q < g0[k] + sz[k]; q++) r += (L.keyB[q] < key[h + k]) ? 1u : 0u;
                 }
-                if (tid + (h + k) * RK_KT < count) rk[(unsigned)key[h + k] & pmask] = rank0 + r;
-                o[h + k] = r;
+                if (on) rk[(unsigned)key[h + k] & pmask] = rank0 + r;
+                so[h + k] = (so[h + k] & 0xFFFFu) | (r << 16);
             }
         }
     } else {
 #pragma unroll
         for (int k = 0; k < RK_KE; k++) {
-            const unsigned j = tid + k * RK_KT;
+            const unsigned j = bucket_slot<PACKED8>(tid, k);
             if (j < count) {
-                const unsigned g0 = L.st[sb[k]], g1 = L.st[sb[k] + 1];
+                const unsigned g0 = L.st[so[k] & 0xFFFFu], g1 = L.st[(so[k] & 0xFFFFu) + 1];
                 unsigned r = g0;
                 if (g1 - g0 > 1) {
                     const unsigned long long mine = key[k] >> PB;
@@ -410,13 +616,13 @@ __device__ __forceinline__ void bucket_ranks(BucketLds<LGNSB>& L, unsigned long 
                         const unsigned long long kq = L.keyB[q];
                         if ((kq >> PB) != mine) r += ((kq >> PB) < mine) ? 1u : 0u;
                         else if (kq != key[k]) {      // an equal magnitude in another slot: the home indices decide
-                            if (myid == 0xFFFFFFFFu) myid = ii[j];
-                            r += (ii[(unsigned)kq & pmask] < myid) ? 1u : 0u;
+                            if (myid == 0xFFFFFFFFu) myid = home(j);
+                            r += (home((unsigned)kq & pmask) < myid) ? 1u : 0u;
                         }
                     }
                 }
-                rk[ii[j]] = rank0 + r;
-                o[k] = r;
+                rk[home(j)] = rank0 + r;
+                so[k] = (so[k] & 0xFFFFu) | (r << 16);
             }
         }
     }
@@ -429,9 +635,11 @@ __device__ __forceinline__ void bucket_ranks(BucketLds<LGNSB>& L, unsigned long 
 // 1D grid of nbmax * (examples rounded up to 8) workgroups: consecutive workgroups go to consecutive XCDs, so
 // workgroup L works on example (L / 8 / nbmax) * 8 + L % 8 -- all buckets of an example share one XCD, whose L2
 // then collects the example's scattered ranks into whole lines.
-template <int LGNSB>
-__global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned long long* __restrict__ mag, const unsigned* __restrict__ idx, size_t n, int lgn,
-                                                    unsigned* meta_all, unsigned* rank, int B, const unsigned* flag, int NF, int lgBPO) {
+// PACKED8: the staging holds kr_part8's keys (mag) and cursor snapshots (snap); wide buckets read their magnitudes from Y.
+template <int LGNSB, bool PACKED8>
+__global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned long long* __restrict__ mag, const unsigned* __restrict__ idx,
+                                                                 const unsigned short* __restrict__ snap, const double* __restrict__ Y, size_t n, int lgn,
+                                                                 unsigned* meta_all, unsigned* rank, int B, const unsigned* flag, int NF, int lgBPO) {
     constexpr int NSB = 1 << LGNSB;
     constexpr int SPT = NSB / RK_KT;            // sub-bins per thread in the prefix sum
     static_assert(SPT % 4 == 0 && RK_CAP == RK_KE * RK_KT, "whole 16-byte pieces of counters per thread; RK_KE magnitudes per thread");
@@ -450,12 +658,13 @@ __global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned l
     const unsigned long long* mi = mag + (size_t)e * n + s0;
     const unsigned* ii = idx + (size_t)e * n + s0;
     unsigned long long key[RK_KE];
-    unsigned id[RK_KE], o[RK_KE], sb[RK_KE];
+    unsigned id[RK_KE], so[RK_KE];
+    static_assert(LGNSB <= 16 && RK_CAP <= 65535, "sub-bin and place share a register");
 #pragma unroll
     for (int k = 0; k < RK_KE; k++) {
-        const unsigned j = min((unsigned)(tid + k * RK_KT), count - 1u);   // (slots beyond the bucket repeat its last magnitude and are left out below)
+        const unsigned j = min(bucket_slot<PACKED8>(tid, k), count - 1u);   // (slots beyond the bucket repeat its last magnitude and are left out below)
         key[k] = mi[j];
-        id[k] = ii[j];
+        if constexpr (!PACKED8) id[k] = ii[j];
     }
     {
         uint4* z = reinterpret_cast<uint4*>(L.st) + tid * (SPT / 4);
@@ -467,14 +676,51 @@ __global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned l
     const unsigned f0 = meta_binfirst(meta, nbmax)[b], fnext = meta_binfirst(meta, nbmax)[b + 1];
     unsigned long long lo, hi;
     bin_range(f0, (fnext > f0 ? fnext : (unsigned)NF) - 1u, meta[2], meta[3], lgBPO, NF, &lo, &hi);
+    const int steps = (int)(n >> RK_IB);
+    if constexpr (PACKED8) {
+        // the bucket's column of cursor snapshots; a slot's step is the last one whose snapshot does not exceed it
+        const int nbe = nbmax_even(n);
+        const unsigned short* sc = snap + (size_t)e * steps * nbe + b;
+        for (int r = tid; r < steps; r += RK_KT) L.col[r] = sc[(size_t)r * nbe];
+        if (tid == 0) L.col[steps] = (unsigned short)count;
+        lds_barrier();
+        const bool wide = ((hi - lo) >> (64 - RK_IB)) != 0;      // kr_part8 could not keep this bucket's magnitudes whole
+        // A wave's slots are 512 consecutive ones, 64 per k, and the regions' boundaries are the same for every lane: the
+        // region of a block's first slot and the boundaries inside the block are followed in scalar registers (reads of
+        // one LDS address by the whole wave), and a lane only counts the boundaries that do not exceed its slot.
+        const BucketHomes<true> first{nullptr, mi, L.col, steps};
+        const unsigned base0 = (unsigned)__builtin_amdgcn_readfirstlane((int)bucket_slot<true>(tid & ~63, 0));
+        unsigned rs = (base0 < count) ? first.step_of(base0) : 0u;
+        rs = (unsigned)__builtin_amdgcn_readfirstlane((int)rs);
+#pragma unroll
+        for (int k = 0; k < RK_KE; k++) {
+            const unsigned base = base0 + 64u * (unsigned)k, j = base + (unsigned)lane;
+            unsigned bnd = (unsigned)__builtin_amdgcn_readfirstlane((int)L.col[rs + 1]);
+            while (rs + 1 < (unsigned)steps && bnd <= base) {          // the last region that starts at or before the block
+                rs++;
+                bnd = (unsigned)__builtin_amdgcn_readfirstlane((int)L.col[rs + 1]);
+            }
+            unsigned r = rs, t = rs + 1;
+            while (t < (unsigned)steps && bnd < base + 64u) {           // regions that start inside the block
+                r += (j >= bnd) ? 1u : 0u;
+                t++;
+                bnd = (unsigned)__builtin_amdgcn_readfirstlane((int)L.col[t]);
+            }
+            id[k] = (r << RK_IB) | ((unsigned)key[k] & ((1u << RK_IB) - 1u));
+            key[k] = lo + (key[k] >> RK_IB);
+            if (wide && j < count) key[k] = (unsigned long long)__double_as_longlong(Y[(size_t)e * n + id[k]]) & 0x7FFFFFFFFFFFFFFFull;
+        }
+    }
     if (f0 == 0) {
         // the lowest bin reaches down to zero: the bucket's own smallest and largest magnitude instead
         lo = ~0ull;
         hi = 0;
 #pragma unroll
-        for (int k = 0; k < RK_KE; k++) {      // (the repeats beyond the bucket change nothing)
-            lo = key[k] < lo ? key[k] : lo;
-            hi = key[k] > hi ? key[k] : hi;
+        for (int k = 0; k < RK_KE; k++) {
+            if (bucket_slot<PACKED8>(tid, k) < count) {
+                lo = key[k] < lo ? key[k] : lo;
+                hi = key[k] > hi ? key[k] : hi;
+            }
         }
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) {
@@ -500,12 +746,14 @@ __global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned l
     const unsigned long long remmask = sh ? ((1ull << sh) - 1ull) : 0ull;
 #pragma unroll
     for (int k = 0; k < RK_KE; k++) {
-        const unsigned j = tid + k * RK_KT;
+        const unsigned j = bucket_slot<PACKED8>(tid, k);
         const unsigned long long rel = key[k] - lo;
-        sb[k] = (unsigned)(rel >> sh);
+        // (a slot beyond the bucket holds no magnitude of it: sub-bin 0, so that whatever is read for it below is in range)
+        // (and never beyond the last sub-bin: every loop below is then bounded by the bucket's size whatever the staging holds)
+        const unsigned sb = (j < count) ? min((unsigned)(rel >> sh), (unsigned)(NSB - 1)) : 0u;
         key[k] = ((rel & remmask) << PB) | (slots ? j : id[k]);
-        o[k] = 0;
-        if (j < count) o[k] = atomicAdd(&L.st[sb[k]], 1u);
+        so[k] = sb;
+        if (j < count) so[k] = sb | (atomicAdd(&L.st[sb], 1u) << 16);
     }
     lds_barrier();
     {   // counts -> exclusive prefix sums, in place: SPT consecutive sub-bins per thread
@@ -537,18 +785,19 @@ __global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned l
     lds_barrier();
 #pragma unroll
     for (int k = 0; k < RK_KE; k++) {
-        if (tid + k * RK_KT < count) L.keyB[L.st[sb[k]] + o[k]] = key[k];
+        if (bucket_slot<PACKED8>(tid, k) < count) L.keyB[L.st[so[k] & 0xFFFFu] + (so[k] >> 16)] = key[k];
     }
     lds_barrier();
     unsigned* rk = rank + (size_t)e * n;
     const unsigned rank0 = zeros + s0 + 1u;
-    if (!slots) bucket_ranks<LGNSB, false>(L, key, sb, o, count, PB, ii, rk, rank0);
-    else bucket_ranks<LGNSB, true>(L, key, sb, o, count, PB, ii, rk, rank0);
+    const BucketHomes<PACKED8> home{ii, mi, L.col, steps};
+    if (!slots) bucket_ranks<LGNSB, false, PACKED8>(L, key, so, count, PB, home, rk, rank0);
+    else bucket_ranks<LGNSB, true, PACKED8>(L, key, so, count, PB, home, rk, rank0);
     lds_barrier();       // every comparison has read its keys: the array now takes the magnitudes in sorted order
     unsigned long long* magS = L.keyB;
 #pragma unroll
     for (int k = 0; k < RK_KE; k++) {
-        if (tid + k * RK_KT < count) magS[o[k]] = lo + ((unsigned long long)sb[k] << sh) + (key[k] >> PB);
+        if (bucket_slot<PACKED8>(tid, k) < count) magS[so[k] >> 16] = lo + ((unsigned long long)(so[k] & 0xFFFFu) << sh) + (key[k] >> PB);
     }
     lds_barrier();
     double f = 0, a = 0;
