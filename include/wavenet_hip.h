@@ -68,6 +68,8 @@ int wn_destroy(wn_context* ctx);
  * (null) stream. */
 int wn_set_stream(wn_context* ctx, void* hip_stream);
 int wn_synchronize(wn_context* ctx);
+/* The GPU a context was created on. */
+int wn_get_device(wn_context* ctx, int* device);
 const char* wn_last_error(const wn_context* ctx);
 const char* wn_status_string(int status);
 
@@ -217,6 +219,15 @@ int wn_num_updates(wn_context* ctx, int* steps);
  * update, costs_host[count] the batch-mean costs.  Either may be NULL.  Synchronises.
  */
 int wn_get_logs(wn_context* ctx, int first, int count, double* filters_host, double* costs_host);
+/*
+ * Everything the host side of Wavenet::train / flushBatchQueue_ (src/Wavenet.cxx:219-242, 717-765) keeps after a
+ * run of batches -- m_filterLog and m_costLog entries, m_momentum, and whether an update was refused -- in ONE
+ * readback: *steps = number of updates applied so far; the log entries [first, min(first + max_count, *steps)) as
+ * wn_get_logs gives them; momentum_host[N].  Any of the three arrays may be NULL.  Returns WN_ERR_NONFINITE, with
+ * all outputs filled in, once a batch was rejected for non-finite sums.  Synchronises.
+ */
+int wn_get_updates(wn_context* ctx, int first, int max_count, int* steps, double* filters_host, double* costs_host,
+                   double* momentum_host);
 int wn_clear_logs(wn_context* ctx);
 
 /*
@@ -255,6 +266,14 @@ int wn_generate_needle(wn_context* ctx, unsigned long long seed, long long first
 int wn_generate_calorimeter(wn_context* ctx, unsigned long long seed, long long first_example,
                             int B, int R, int C, const int* poisson_table_host,
                             const double* energy_table_host, int jets, int jet_deposits, double* X_dev);
+/*
+ * GaussianGenerator (include/Wavenet/Generators.h:122-166): one to three unit-height Gaussian bumps of random
+ * centre and width per example.  exp_table_host[i] = exp(-i / 128), i = 0 .. 4096 (4097 entries): the bumps are
+ * evaluated from it by linear interpolation, with the same arithmetic as the host layer's GaussianGenerator, so
+ * that the two agree to the bit whatever the libm.  The table is kept on the device until a different one is passed.
+ */
+int wn_generate_gaussian(wn_context* ctx, unsigned long long seed, long long first_example, int B, int R, int C,
+                         const double* exp_table_host, double* X_dev);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 /*

@@ -4,12 +4,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
 #include "Wavenet/Coach.h"
 #include "Wavenet/Generators.h"
 #include "Wavenet/Wavenet.h"
+#include "wavenet_hip.h"
 
 using namespace wavenet;
 
@@ -231,6 +233,85 @@ int main(int argc, char** argv) {
             g_prefix = "snap_";
             dumpLogs(v);
         }
+        return 0;
+    }
+    if (mode == "generate") {
+        // generate <kind> R C count seed: `count` examples from next() and the same from nextOnDevice, as "host" and "device"
+        const std::string kind = argv[2];
+        const unsigned R = std::atoi(argv[3]), C = std::atoi(argv[4]), count = std::atoi(argv[5]);
+        const unsigned long long seed = std::strtoull(argv[6], nullptr, 10);
+        UniformGenerator u; NeedleGenerator nd; GaussianGenerator ga; CalorimeterGenerator ca;
+        SeededGenerator* gen = kind == "uniform" ? (SeededGenerator*)&u : kind == "needle" ? (SeededGenerator*)&nd
+                             : kind == "gaussian" ? (SeededGenerator*)&ga : (SeededGenerator*)&ca;
+        gen->setSeed(seed);
+        if (!gen->setShape({R, C})) return 3;
+        const size_t n = (size_t)R * C;
+        std::vector<double> host(count * n), dev(count * n);
+        for (unsigned e = 0; e < count; e++) std::memcpy(host.data() + e * n, gen->next().memptr(), n * sizeof(double));
+        dump("host", host.data(), host.size());
+        if (!std::getenv("WAVENET_TEST_HOST_ONLY")) {
+            wn_context* ctx = nullptr;
+            double* dX = nullptr;
+            if (wn_create(0, &ctx) != WN_OK || wn_malloc(ctx, (void**)&dX, dev.size() * sizeof(double)) != WN_OK) return 4;
+            gen->reset();
+            if (!gen->nextOnDevice(ctx, dX, count)) return 5;
+            if (wn_memcpy_d2h(ctx, dev.data(), dX, dev.size() * sizeof(double)) != WN_OK) return 6;
+            dump("device", dev.data(), dev.size());
+            wn_free(ctx, dX);
+            wn_destroy(ctx);
+        }
+        return 0;
+    }
+    if (mode == "bench") {
+        // bench R C N batch events epochs flags source kind: times Coach::run() (the reference's training entry point,
+        // src/Coach.cxx:71-296) end to end and prints one JSON line.  source: "resident" (a fixed set of `events`
+        // examples generated once on the device and served from there every epoch, as a file-based generator of the
+        // reference would serve its file) or "generated" (every chunk drawn from the generator on the device).
+        const unsigned R = std::atoi(argv[2]), C = std::atoi(argv[3]), N = std::atoi(argv[4]), batch = std::atoi(argv[5]);
+        const int events = std::atoi(argv[6]);
+        const unsigned epochs = std::atoi(argv[7]), flags = std::atoi(argv[8]);
+        const std::string source = argv[9], kind = argv[10];
+        std::vector<double> in = readAll(argv[11]);
+        UniformGenerator u; NeedleGenerator nd; GaussianGenerator ga; CalorimeterGenerator ca;
+        SeededGenerator* base = kind == "uniform" ? (SeededGenerator*)&u : kind == "needle" ? (SeededGenerator*)&nd
+                              : kind == "gaussian" ? (SeededGenerator*)&ga : (SeededGenerator*)&ca;
+        base->setSeed(1000);
+        if (!base->setShape({R, C})) return 3;
+        ResidentGenerator resident(*base, (unsigned)events);
+        GeneratorBase* gen = source == "resident" ? (GeneratorBase*)&resident : (GeneratorBase*)base;
+        double best = 0, updates = 0, lastCost = 0;
+        std::vector<double> finalFilter;
+        for (int rep = 0; rep < 3; rep++) {       // the first run also allocates, generates the resident set and loads the kernels
+            Wavenet w(10.0, 1e-3);
+            w.setBatchSize(batch);
+            Coach coach("bench");
+            coach.setWavenet(&w);
+            coach.setGenerator(gen);
+            coach.setNumEvents(source == "resident" ? -1 : events);
+            coach.setNumEpochs(rep == 0 ? 1 : epochs);
+            coach.setNumCoeffs(N);
+            coach.setInitialFilter(Col(N, in.data()));
+            coach.setUseAdaptiveLearningRate(flags & 1u);
+            coach.setUseAdaptiveBatchSize((flags >> 1) & 1u);
+            coach.setPrintLevel(0);
+            struct timespec t0, t1;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
+            if (!coach.run()) return 4;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if (rep == 0) continue;
+            const double s = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+            const double rate = (double)events * epochs / s;
+            if (rate > best) best = rate;
+            updates = (double)w.costLog().size();
+            lastCost = w.lastCost();
+            const Col f = w.filter();
+            finalFilter.assign(f.memptr(), f.memptr() + N);
+        }
+        std::printf("{\"coach_run_examples_per_s\": %.1f, \"shape\": [%u, %u], \"taps\": %u, \"batch\": %u, \"events_per_epoch\": %d, "
+                    "\"epochs\": %u, \"adaptive_flags\": %u, \"source\": \"%s\", \"generator\": \"%s\", \"updates\": %.0f, "
+                    "\"last_cost\": %.12g, \"final_filter_0\": %.17g}\n",
+                    best, R, C, N, batch, events, epochs, flags, source.c_str(), kind.c_str(), updates, lastCost,
+                    finalFilter.empty() ? 0.0 : finalFilter[0]);
         return 0;
     }
     return 2;

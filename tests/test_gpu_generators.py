@@ -103,3 +103,43 @@ def test_calorimeter_tables_survive_a_cost_grid():
     torch.cuda.synchronize()
     assert np.array_equal(from_dev(d, B, R, C), ref)
     c.close()
+
+
+@pytest.mark.parametrize("R,C,B", [(64, 64, 7), (1024, 1, 3), (16, 256, 4)])
+def test_gaussian(ctx, R, C, B):
+    """The Gaussian bumps written on the device are those of generators.gaussian: the same table of exp and the same
+    additions and multiplications on both sides."""
+    import torch
+    from wavenet_amd import generators as G
+    first, seed = 3, 21
+    d = dev_empty(B * R * C)
+    ctx.generate_gaussian(d, B, R, C, seed=seed, first=first)
+    torch.cuda.synchronize()
+    ref = G.gaussian(first + B, R, C, seed=seed)[first:]
+    assert np.array_equal(from_dev(d, B, R, C), ref)
+    assert ref.max() <= 3.0 + 1e-12 and ref.max() > 0.5
+
+
+@pytest.mark.parametrize("kind,R,C", [("gaussian", 32, 64), ("calorimeter", 64, 64), ("calorimeter", 128, 64), ("needle", 16, 16),
+                                      ("uniform", 8, 32)])
+def test_host_layer_generators_agree_with_their_device_forms(kind, R, C):
+    """next() and nextOnDevice() of the C++ host layer's generators (tests/cpp/host_driver generate): bit-identical,
+    calorimeter images of up to 4096 bins through the LDS kernel and larger ones through the one that works in
+    memory.  The calorimeter images also match generators.calorimeter wherever the C library's log and exp agree
+    with numpy's to the bit; a difference of an ulp in a table entry is accepted."""
+    from test_host_cpp import run_driver
+    from wavenet_amd import generators as G
+    count, seed = 5, 1000
+    out, _ = run_driver(["generate", kind, R, C, count, seed], [np.zeros(1)])
+    assert np.array_equal(out["host"], out["device"])
+    X = out["host"].reshape(count, C, R).transpose(0, 2, 1)        # column-major examples -> (B, R, C)
+    if kind == "calorimeter":
+        ref = G.calorimeter(count, R, C, seed=seed)
+        assert np.allclose(X, ref, rtol=3e-7, atol=0)               # (bin contents are floats: one float ulp)
+        assert (X != 0).mean() < 0.2
+    elif kind == "gaussian":
+        assert np.allclose(X, G.gaussian(count, R, C, seed=seed), rtol=1e-14, atol=1e-300)
+    elif kind == "uniform":
+        assert np.array_equal(X, G.uniform(count, R, C, seed=seed))
+    else:
+        assert np.array_equal(X, G.needle(count, R, C, seed=seed))

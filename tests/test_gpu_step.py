@@ -99,3 +99,38 @@ def test_train_step_rejects_a_diverging_batch():
     c.train_step(X, B, R, C, B, 10.0 * B, 1e-3, 0.0, True)
     assert c.num_updates() >= 1
     c.close()
+
+
+def test_get_updates_is_the_logs_the_momentum_and_the_verdict_in_one_readback():
+    """wn_get_updates against wn_num_updates + wn_get_logs + wn_get_momentum: a window of the log that starts after
+    the first updates, a window larger than what exists, the log ring wrapped around (more than 16384 updates), and
+    the refusal of a non-finite batch reported with the data still filled in."""
+    import torch
+    R, C, N, B = 8, 8, 4, 16
+    a = F.perturbed(F.DB4, 1e-2, 3)
+    rng = np.random.default_rng(5)
+    dX = to_dev(rng.random((B, R, C)))
+    c = _ctx()
+    c.set_filter(a)
+    for _ in range(40):
+        c.train_step(dX, B, R, C, B, 10.0 * B, 1e-3, 0.3, True)
+    Fl, Cl = c.logs()
+    steps, Fw, Cw, P, rejected = c.updates(first=25, max_count=100)
+    assert steps == 40 and not rejected
+    assert np.array_equal(Fw, Fl[25:]) and np.array_equal(Cw, Cl[25:]) and np.array_equal(P, c.momentum())
+    steps, Fw, Cw, P, _ = c.updates(first=0, max_count=7)
+    assert steps == 40 and np.array_equal(Fw, Fl[:7]) and np.array_equal(Cw, Cl[:7])
+    # the ring of 16384 entries wrapped: the newest entries are still there
+    for _ in range(16400):
+        c.train_step(dX, B, R, C, B, 10.0 * B, 1e-6, 0.0, True)
+    steps, Fw, Cw, P, _ = c.updates(first=16430, max_count=10)
+    assert steps == 16440
+    F2, C2 = c.logs(first=16430, count=10)
+    assert np.array_equal(Fw, F2) and np.array_equal(Cw, C2) and np.array_equal(Fw[-1], c.filter())
+    # a batch that is refused
+    bad = rng.random((B, R, C))
+    bad[3, 2, 2] = np.inf
+    c.train_step(to_dev(bad), B, R, C, B, 10.0 * B, 1e-3, 0.0, True)
+    steps, Fw, Cw, P, rejected = c.updates(first=16438, max_count=10)
+    assert rejected and steps == 16440 and len(Fw) == 2 and np.array_equal(Fw[-1], c.filter())
+    c.close()

@@ -243,3 +243,28 @@ def test_coach_writes_snapshots():
         assert os.path.exists(os.path.join(tmp, "driver", "snapshots", "driver.000000.snap"))
     for key in ("filterLog", "costLog", "filter", "momentum", "misc"):
         assert np.array_equal(out["snap_" + key], out[key]), key
+
+
+def test_coach_bench_mode_resident_and_generated_sources_agree():
+    """tests/cpp/host_driver bench: Coach::run over a fixed set of examples that sits on the device (ResidentGenerator,
+    trained where it is, logs fetched once per epoch) and over the same examples drawn from the generator chunk by
+    chunk must end at the same filter and cost."""
+    import json
+    a = F.perturbed(F.DB4, 1e-2, 7)
+
+    def bench(source, kind="calorimeter"):
+        with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+            np.asarray(a, dtype=np.float64).tofile(f)
+            path = f.name
+        try:
+            res = subprocess.run([DRIVER, "bench", "64", "64", "4", "32", "256", "1", "0", source, kind, path],
+                                 capture_output=True, text=True, timeout=300)
+        finally:
+            os.unlink(path)
+        assert res.returncode == 0, (res.stdout[-500:], res.stderr[-2000:])
+        return json.loads(res.stdout.strip().splitlines()[-1])
+
+    r, g = bench("resident"), bench("generated")
+    assert r["updates"] == g["updates"] == 8            # 256 events / 32 per batch, cost log after pop_back
+    assert r["final_filter_0"] == g["final_filter_0"] and r["last_cost"] == g["last_cost"]
+    assert r["coach_run_examples_per_s"] > 0 and np.isfinite(r["last_cost"])

@@ -49,6 +49,8 @@ SIGNATURES = {
     "wn_generate_needle": (C.c_int, [_vp, C.c_ulonglong, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_double, _vp]),
     "wn_generate_calorimeter": (C.c_int, [_vp, C.c_ulonglong, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                           C.POINTER(C.c_int), _dp, C.c_int, C.c_int, _vp]),
+    "wn_get_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "wn_generate_gaussian": (C.c_int, [_vp, C.c_ulonglong, C.c_longlong, C.c_int, C.c_int, C.c_int, _dp, _vp]),
     "wn_train_batch": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "wn_train_batch_static": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "wn_sums": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_int)]),
@@ -60,6 +62,7 @@ SIGNATURES = {
     "wn_train_step": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]),
     "wn_num_updates": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "wn_get_logs": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp]),
+    "wn_get_updates": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int), _dp, _dp, _dp]),
     "wn_clear_logs": (C.c_int, [_vp]),
     "wn_comm_unique_id": (C.c_int, [_vp]),
     "wn_comm_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
@@ -259,6 +262,12 @@ class Context:
         self._check(self.lib.wn_generate_calorimeter(self._h, seed, first, B, R, Cc, ptab.ctypes.data_as(C.POINTER(C.c_int)),
                                                      etab.ctypes.data_as(_dp), jets, jet_deposits, _addr(X)))
 
+    def generate_gaussian(self, X, B, R, Cc, seed=1, first=0):
+        """wn_generate_gaussian: the sequence of generators.gaussian, written on the device."""
+        from .generators import GAUSS_EXP_TABLE
+        tab = np.ascontiguousarray(GAUSS_EXP_TABLE, dtype=np.float64)
+        self._check(self.lib.wn_generate_gaussian(self._h, seed, first, B, R, Cc, tab.ctypes.data_as(_dp), _addr(X)))
+
     # training -----------------------------------------------------------------------------------
     def train_batch(self, X, B, R, Cc, grad=None, S=None):
         self._check(self.lib.wn_train_batch(self._h, _addr(X), B, R, Cc, _addr(grad), _addr(S)))
@@ -315,6 +324,20 @@ class Context:
         Cs = np.empty(count)
         self._check(self.lib.wn_get_logs(self._h, first, count, F.ctypes.data_as(_dp), Cs.ctypes.data_as(_dp)))
         return F, Cs
+
+    def updates(self, first=0, max_count=1024):
+        """wn_get_updates: (steps, filters[count][N], costs[count], momentum[N], rejected) in one readback."""
+        N = len(self.filter())
+        F = np.empty((max_count, N))
+        Cs = np.empty(max_count)
+        P = np.empty(N)
+        n = C.c_int(0)
+        st = self.lib.wn_get_updates(self._h, first, max_count, C.byref(n), F.ctypes.data_as(_dp), Cs.ctypes.data_as(_dp),
+                                     P.ctypes.data_as(_dp))
+        if st not in (0, WN_ERR_NONFINITE):
+            self._check(st)
+        count = max(0, min(max_count, n.value - first))
+        return n.value, F[:count], Cs[:count], P, st == WN_ERR_NONFINITE
 
     def clear_logs(self):
         self._check(self.lib.wn_clear_logs(self._h))

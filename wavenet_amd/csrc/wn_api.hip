@@ -192,6 +192,24 @@ __global__ __launch_bounds__(1024) void k_finish(const double* partial, int nslo
     if (S.mode == 2) wn::update_body(S.filt, state, ssum, S.P, sh, tid);
 }
 
+// The update state in one piece for a single copy to the host: out[0] = number of updates, out[1] = non-finite flag,
+// out[2 .. 2 + MAXTAPS) = momentum, then for the updates first .. min(first + max_count, updates) - 1 rows of
+// MAXTAPS + 1 doubles: the filter after the update and the batch's mean cost.
+__global__ __launch_bounds__(256) void k_pack_updates(const wn::FilterDev* f, const double* logF, const double* logC, int first, int max_count,
+                                                      int cap, double* out) {
+    const int steps = f->steps;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) { out[0] = (double)steps; out[1] = (double)f->nonfinite; }
+        if (threadIdx.x < wn::MAXTAPS) out[2 + threadIdx.x] = f->momentum[threadIdx.x];
+    }
+    const int count = min(max_count, steps - first);
+    constexpr int ROW = wn::MAXTAPS + 1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count * ROW; i += gridDim.x * blockDim.x) {
+        const int r = i / ROW, c = i % ROW, idx = (first + r) % cap;
+        out[2 + wn::MAXTAPS + i] = (c < wn::MAXTAPS) ? logF[(size_t)idx * wn::MAXTAPS + c] : logC[idx];
+    }
+}
+
 __global__ void k_reset_steps(wn::FilterDev* f) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { f->steps = 0; f->nonfinite = 0; }
 }
@@ -312,12 +330,15 @@ int wn_destroy(wn_context* ctx) {
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     (void)hipFree(ctx->workspace);
     if (ctx->gen_tables) (void)hipFree(ctx->gen_tables);
+    free(ctx->gen_tables_host);
     if (ctx->grid_filters) (void)hipFree(ctx->grid_filters);
     if (ctx->grid_scratch) (void)hipFree(ctx->grid_scratch);
     for (hipEvent_t ev : ctx->prof_begin) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->prof_end) (void)hipEventDestroy(ev);
     (void)hipFree(ctx->log_filters);
     (void)hipFree(ctx->log_costs);
+    if (ctx->pack_dev) (void)hipFree(ctx->pack_dev);
+    if (ctx->pack_host) (void)hipHostFree(ctx->pack_host);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return WN_OK;
@@ -338,6 +359,12 @@ int wn_synchronize(wn_context* ctx) {
     wn::make_current(ctx);
     if (!ctx) return WN_ERR_ARG;
     WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WN_OK;
+}
+
+int wn_get_device(wn_context* ctx, int* device) {
+    if (!ctx || !device) return WN_ERR_ARG;
+    *device = ctx->device;
     return WN_OK;
 }
 
@@ -892,30 +919,72 @@ int wn_num_updates(wn_context* ctx, int* steps) {
     return WN_OK;
 }
 
+// Gathers the update state on the device (k_pack_updates) and brings it over in ONE copy into the context's pinned
+// buffer; returns the device's update count and flag.  rows: log entries wanted from `first` on.
+static int fetch_updates(wn_context* ctx, int first, int rows, int* steps, int* nonfinite) {
+    constexpr size_t ROW = wn::MAXTAPS + 1;
+    const size_t need = 2 + wn::MAXTAPS + (size_t)rows * ROW;
+    if (need > ctx->pack_doubles) {
+        if (ctx->pack_dev) (void)hipFree(ctx->pack_dev);
+        if (ctx->pack_host) (void)hipHostFree(ctx->pack_host);
+        ctx->pack_dev = ctx->pack_host = nullptr;
+        ctx->pack_doubles = 0;
+        const size_t cap = std::max<size_t>(need, 2 + wn::MAXTAPS + 1024 * ROW);
+        WN_HIP(ctx, hipMalloc((void**)&ctx->pack_dev, cap * sizeof(double)));
+        WN_HIP(ctx, hipHostMalloc((void**)&ctx->pack_host, cap * sizeof(double), hipHostMallocDefault));
+        ctx->pack_doubles = cap;
+    }
+    const int blocks = std::max(1, std::min(64, (int)((size_t)rows * ROW / 256)));
+    hipLaunchKernelGGL(k_pack_updates, dim3(blocks), dim3(256), 0, ctx->stream, ctx->dfilt, ctx->log_filters, ctx->log_costs, first, rows,
+                       kLogCap, ctx->pack_dev);
+    WN_HIP(ctx, hipGetLastError());
+    WN_HIP(ctx, hipMemcpyAsync(ctx->pack_host, ctx->pack_dev, need * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    WN_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *steps = (int)ctx->pack_host[0];
+    *nonfinite = (int)ctx->pack_host[1];
+    return WN_OK;
+}
+
+static void unpack_rows(const wn_context* ctx, int count, double* filters, double* costs) {
+    constexpr size_t ROW = wn::MAXTAPS + 1;
+    const double* rows = ctx->pack_host + 2 + wn::MAXTAPS;
+    const int N = ctx->N;
+    for (int i = 0; i < count; i++) {
+        if (filters) memcpy(filters + (size_t)i * N, rows + (size_t)i * ROW, (size_t)N * sizeof(double));
+        if (costs) costs[i] = rows[(size_t)i * ROW + wn::MAXTAPS];
+    }
+}
+
 int wn_get_logs(wn_context* ctx, int first, int count, double* filters, double* costs) {
     wn::make_current(ctx);
     if (!ctx || first < 0 || count < 0) return WN_ERR_ARG;
     if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
     int steps = 0, bad = 0;
-    int rc = read_update_state(ctx, &steps, &bad);
+    const int rc = fetch_updates(ctx, first, count, &steps, &bad);
     if (rc) return rc;
     if (first + count > steps || steps - first > kLogCap)
         return fail(ctx, WN_ERR_ARG, "log range not available (" + std::to_string(steps) + " updates, ring of " +
                                          std::to_string(kLogCap) + ")");
-    const int N = ctx->N;
-    double row[wn::MAXTAPS];
-    for (int i = 0; i < count; i++) {
-        const int idx = (first + i) % kLogCap;
-        if (filters) {
-            rc = wn_memcpy_d2h(ctx, row, ctx->log_filters + (size_t)idx * wn::MAXTAPS, sizeof(row));
-            if (rc) return rc;
-            memcpy(filters + (size_t)i * N, row, (size_t)N * sizeof(double));
-        }
-        if (costs) {
-            rc = wn_memcpy_d2h(ctx, costs + i, ctx->log_costs + idx, sizeof(double));
-            if (rc) return rc;
-        }
-    }
+    unpack_rows(ctx, count, filters, costs);
+    return WN_OK;
+}
+
+int wn_get_updates(wn_context* ctx, int first, int max_count, int* steps_out, double* filters, double* costs, double* momentum) {
+    wn::make_current(ctx);
+    if (!ctx || first < 0 || max_count < 0 || !steps_out) return WN_ERR_ARG;
+    if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
+    int steps = 0, bad = 0;
+    const int rc = fetch_updates(ctx, first, max_count, &steps, &bad);
+    if (rc) return rc;
+    *steps_out = steps;
+    if (steps < first || steps - first > kLogCap)
+        return fail(ctx, WN_ERR_ARG, "log range not available (" + std::to_string(steps) + " updates, ring of " +
+                                         std::to_string(kLogCap) + ")");
+    unpack_rows(ctx, std::min(max_count, steps - first), filters, costs);
+    if (momentum) memcpy(momentum, ctx->pack_host + 2, (size_t)ctx->N * sizeof(double));
+    if (bad)
+        return fail(ctx, WN_ERR_NONFINITE, "a batch gave non-finite sums and was not applied (most likely a diverging "
+                                           "solution: lower alpha or lambda); no update is applied until wn_set_filter or wn_clear_logs");
     return WN_OK;
 }
 
@@ -959,6 +1028,8 @@ int wn_comm_init(wn_context* ctx, const void* id128, int nranks, int rank) {
     ctx->nccl_lib = lib;
     ctx->comm = comm;
     ctx->nranks = nranks;
+    ctx->fn_allreduce = dlsym(lib, "ncclAllReduce");
+    if (!ctx->fn_allreduce) return fail(ctx, WN_ERR_COMM, "ncclAllReduce not found");
     return WN_OK;
 }
 
@@ -986,10 +1057,17 @@ int wn_comm_init_all(wn_context** ctxs, int n) {
     for (int r = 0; r < n; r++) devs[(size_t)r] = ctxs[r]->device;
     const int rc = f(comms.data(), n, devs.data());
     if (rc != 0) return fail(ctxs[0], WN_ERR_COMM, "ncclCommInitAll failed: " + std::to_string(rc));
+    void* ar = dlsym(lib, "ncclAllReduce");
+    void* gs = dlsym(lib, "ncclGroupStart");
+    void* ge = dlsym(lib, "ncclGroupEnd");
+    if (!ar || !gs || !ge) return fail(ctxs[0], WN_ERR_COMM, "ncclAllReduce / ncclGroupStart / ncclGroupEnd not found");
     for (int r = 0; r < n; r++) {
         ctxs[r]->nccl_lib = lib;
         ctxs[r]->comm = comms[(size_t)r];
         ctxs[r]->nranks = n;
+        ctxs[r]->fn_allreduce = ar;
+        ctxs[r]->fn_group_start = gs;
+        ctxs[r]->fn_group_end = ge;
     }
     return WN_OK;
 }
@@ -1001,11 +1079,11 @@ int wn_allreduce_sums_all(wn_context** ctxs, int n) {
         if (!ctxs[r]->has_filter) return fail(ctxs[r], WN_ERR_STATE, "no filter set");
         if (!ctxs[r]->comm || ctxs[r]->nranks != n) return fail(ctxs[r], WN_ERR_STATE, "no communicator over these contexts: call wn_comm_init_all first");
     }
-    void* lib = ctxs[0]->nccl_lib;
-    auto ar = (fn_ncclAllReduce)dlsym(lib, "ncclAllReduce");
-    auto gs = (fn_ncclGroup)dlsym(lib, "ncclGroupStart");
-    auto ge = (fn_ncclGroup)dlsym(lib, "ncclGroupEnd");
-    if (!ar || !gs || !ge) return fail(ctxs[0], WN_ERR_COMM, "ncclAllReduce / ncclGroupStart / ncclGroupEnd not found");
+    // (entry points looked up once, in wn_comm_init_all: this call sits on the serial path of every batch)
+    auto ar = (fn_ncclAllReduce)ctxs[0]->fn_allreduce;
+    auto gs = (fn_ncclGroup)ctxs[0]->fn_group_start;
+    auto ge = (fn_ncclGroup)ctxs[0]->fn_group_end;
+    if (!ar || !gs || !ge) return fail(ctxs[0], WN_ERR_STATE, "no grouped communicator over these contexts: call wn_comm_init_all first");
     int rc = gs();
     for (int r = 0; r < n && rc == 0; r++) {
         wn_context* c = ctxs[r];
@@ -1033,7 +1111,7 @@ int wn_allreduce_sums(wn_context* ctx) {
     if (!ctx) return WN_ERR_ARG;
     if (!ctx->has_filter) return fail(ctx, WN_ERR_STATE, "no filter set");
     if (!ctx->comm) return fail(ctx, WN_ERR_STATE, "no communicator: call wn_comm_init first");
-    auto f = (fn_ncclAllReduce)dlsym(ctx->nccl_lib, "ncclAllReduce");
+    auto f = (fn_ncclAllReduce)ctx->fn_allreduce;     // looked up when the communicator was made
     if (!f) return fail(ctx, WN_ERR_COMM, "ncclAllReduce not found");
     const int r = f(ctx->sums, ctx->sums, (size_t)(ctx->N + 2), kNcclDouble, kNcclSum, ctx->comm, ctx->stream);
     if (r != 0) return fail(ctx, WN_ERR_COMM, "ncclAllReduce failed: " + std::to_string(r));

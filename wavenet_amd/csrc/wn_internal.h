@@ -22,7 +22,8 @@ struct wn_context {
     int N = 0, NP = 0;
     double* partial = nullptr;
     int partial_blocks = 0;
-    void* gen_tables = nullptr;               // Poisson and energy tables of wn_generate_calorimeter
+    void* gen_tables = nullptr;               // device copies of the generators' tables (Poisson, energy, exp) ...
+    void* gen_tables_host = nullptr;          // ... and what was last uploaded, so that an unchanged table is not sent again
     wn::FilterDev* grid_filters = nullptr;   // table of filters for wn_sparse_cost_grid
     int grid_filters_cap = 0;
     double* grid_scratch = nullptr;           // coefficients of one batch (shapes without a fused cost kernel)
@@ -45,6 +46,12 @@ struct wn_context {
     int prof_used = 0;
     double* log_filters = nullptr;
     double* log_costs = nullptr;
+    double* pack_dev = nullptr;      // wn_get_updates: the update state gathered on the device ...
+    double* pack_host = nullptr;     // ... and its pinned host copy (pack_doubles each)
+    size_t pack_doubles = 0;
+    void* fn_allreduce = nullptr;    // RCCL entry points, looked up once when the communicator is made
+    void* fn_group_start = nullptr;
+    void* fn_group_end = nullptr;
     void* nccl_lib = nullptr;
     void* comm = nullptr;
     int nranks = 1;

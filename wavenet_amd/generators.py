@@ -109,6 +109,37 @@ def calorimeter(B, R, C, seed=1, mean_deposits=None, jets=2, jet_deposits=30):
     return X.reshape(B, R, C)
 
 
+GAUSS_EXP_TABLE = np.exp(-np.arange(4097) / 128.0)       # exp(-t) at t = i / 128, interpolated linearly
+
+
+def _table_exp_neg(t):
+    x = t * 128.0
+    inside = x < 4096.0
+    xi = np.where(inside, x, 0.0)
+    i = xi.astype(np.int64)
+    fr = xi - i
+    return np.where(inside, GAUSS_EXP_TABLE[i] + fr * (GAUSS_EXP_TABLE[i + 1] - GAUSS_EXP_TABLE[i]), 0.0)
+
+
+def gaussian(B, R, C, seed=1):
+    """GaussianGenerator-like (Generators.h:122-166): one to three unit-height Gaussian bumps of random centre and
+    width per example; exp from a table with linear interpolation, as on the device and in the C++ host layer."""
+    X = np.zeros((B, R, C))
+    r = np.arange(R, dtype=np.float64)[:, None]
+    c = np.arange(C, dtype=np.float64)[None, :]
+    for e in range(B):
+        nb = 1 + int(_hash(seed, e, 0) % np.uint64(3))
+        for b in range(nb):
+            mr = float(_unit(_hash(seed, e, 10 + b))) * R
+            mc = float(_unit(_hash(seed, e, 20 + b))) * C
+            sr = 0.5 + 0.15 * R * float(_unit(_hash(seed, e, 30 + b)))
+            sc = 0.5 + 0.15 * C * float(_unit(_hash(seed, e, 40 + b)))
+            dr = (r - mr) / sr
+            dc = (c - mc) / sc if C > 1 else np.zeros_like(c)
+            X[e] += _table_exp_neg(0.5 * (dr * dr + dc * dc))
+    return X
+
+
 def bumps(B, n, seed=1):
     """1D signals: U[0,1) noise plus one raised-cosine bump of random position, width and height."""
     X = uniform(B, n, 1, seed)[:, :, 0]

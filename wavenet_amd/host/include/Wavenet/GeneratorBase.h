@@ -29,6 +29,12 @@ public:
     // when the generator has no device form; Coach then gathers from next() as usual.
     virtual bool nextOnDevice(wn_context* /*ctx*/, double* /*X_dev*/, unsigned /*count*/) { return false; }
     virtual bool hasDeviceForm() const { return false; }
+    // A generator whose examples already sit in device memory hands out the next `count` of them where they are
+    // (valid until the generator is destroyed) and advances; null: no such storage, use nextOnDevice.
+    virtual const double* deviceSpan(wn_context* /*ctx*/, unsigned /*count*/) { return nullptr; }
+    // Examples left before good() turns false, for generators with a natural end (the reference's file generators,
+    // include/Wavenet/Generators.h:194-241, 368-402); -1: endless.
+    virtual long long remaining() const { return -1; }
 
     bool setShape(const std::vector<unsigned>& shape);
     std::vector<unsigned> shape() const { return m_shape; }

@@ -93,7 +93,16 @@ public:
     bool trainBatch(const double* X, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas = nullptr);
     // The same with the B examples drawn from a generator that can write them on the device
     // (GeneratorBase::nextOnDevice); false without touching anything if it cannot.
-    bool trainBatchFrom(GeneratorBase& generator, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas = nullptr);
+    // With deferLogs the filter log, cost log, filter and momentum of this object are NOT brought back from the device
+    // when the call returns (whole batches only): they follow at the next call without the flag, at sync(), or once
+    // 8192 updates are outstanding.  Nothing but the readback is put off -- the device applies every update as it
+    // comes -- so a loop that takes no decision from the logs (Coach without its adaptive rules) runs without a
+    // host round trip per batch.  A rejected (non-finite) batch is reported when the logs arrive.
+    bool trainBatchFrom(GeneratorBase& generator, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas = nullptr,
+                        bool deferLogs = false);
+    // Brings outstanding logs and state over (no effect when there are none); false when a batch was rejected.
+    bool sync();
+    unsigned pendingUpdates() const { return m_pending; }
     void clear();
 
     /// High-level cost method(s).
@@ -148,7 +157,9 @@ private:
     bool checkShape_(unsigned nRows, unsigned nCols) const;
     // forward + sparsity gradient + backpropagation of `count` examples already on the device,
     // per-example results into the batch queue and the cost log (the slow, exact path of train()).
-    bool trainOnDevice_(const double* dX, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas);
+    bool trainOnDevice_(const double* dX, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas, bool deferLogs = false);
+    bool fetchUpdates_();    // the outstanding updates' logs, the filter and the momentum in one readback (wn_get_updates)
+    bool deviceSteps_();     // makes m_devSteps valid
     bool queueExamples_(const double* X_dev, unsigned count, unsigned nRows, unsigned nCols, const double* lambdas);
     bool diverged_() const;  // prints the reference's "diverging solution" message, returns false
 
@@ -168,6 +179,11 @@ private:
     std::vector<int> m_devices;               // data-parallel: one entry per replica (empty: single device)
     std::vector<DeviceSession*> m_replicas;   // sessions of the replicas 1 .. G-1 (replica 0 is m_session)
     bool m_useRccl = true;
+    // updates queued on the first device whose logs have not been fetched, the regularisation constant in force at the
+    // end of each of them (NaN: unchanged), and the device's update counter as of the last fetch
+    unsigned m_pending = 0;
+    std::vector<double> m_pendingLambda;
+    int m_devSteps = -1;
 };
 
 template <class T>

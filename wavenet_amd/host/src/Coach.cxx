@@ -49,8 +49,8 @@ bool Coach::run() {
         return false;
     }
     if (!m_name.size()) { ERROR("Coach name not set. Exiting."); return false; }
-    if (m_numEvents < 0 && !((useAdaptiveLearningRate() || useAdaptiveBatchSize()) && targetPrecision() > 0.)) {
-        // every generator here is endless, like the reference's Needle/Uniform/Gaussian ones (:94-109)
+    if (m_numEvents < 0 && m_generator->remaining() < 0 && !((useAdaptiveLearningRate() || useAdaptiveBatchSize()) && targetPrecision() > 0.)) {
+        // an endless generator, like the reference's Needle/Uniform/Gaussian ones (:94-109)
         WARNING("The number of events is %d, the generator has no natural epochs and no target precision is set. Exiting.", m_numEvents);
         return false;
     }
@@ -99,8 +99,11 @@ bool Coach::run() {
             while (!done && generatorGood && (event < m_numEvents || m_numEvents < 0)) {
                 // chunk: up to the next flush when decisions depend on it, else many batches at once
                 const unsigned bs = (unsigned)std::max(1, m_wavenet->batchSize());
-                unsigned chunk = adaptive ? bs : bs * std::max(1u, 4096u / bs);
+                // (without the adaptive rules: as many whole batches as fit 2^27 samples, 1 GiB, and a generator call)
+                const unsigned many = (unsigned)std::min<std::size_t>(65535u, std::max<std::size_t>(4096u, ((std::size_t)1 << 27) / n));
+                unsigned chunk = adaptive ? bs : bs * std::max(1u, many / bs);
                 if (m_numEvents >= 0) chunk = std::min<unsigned>(chunk, (unsigned)(m_numEvents - event));
+                if (m_generator->remaining() >= 0) chunk = (unsigned)std::min<long long>(chunk, std::max<long long>(1, m_generator->remaining()));
                 lambdas.resize(chunk);
                 // a generator with a device form writes the chunk where the kernels read it
                 const bool onDevice = m_generateOnDevice && m_generator->hasDeviceForm() && chunk <= 65535u;
@@ -115,8 +118,11 @@ bool Coach::run() {
                             lambdas[got] = m_wavenet->lambda();
                         }
                     }
+                    // nothing here looks at the logs between batches unless the adaptive rules or the per-event print are on:
+                    // they are then fetched once per epoch instead of once per chunk
                     const bool status = m_wavenet->trainBatchFrom(*m_generator, got, nRows, nCols,
-                                                                  useSimulatedAnnealing() ? lambdas.data() : nullptr);
+                                                                  useSimulatedAnnealing() ? lambdas.data() : nullptr,
+                                                                  !adaptive && m_printLevel <= 2);
                     if (!m_generator->good()) generatorGood = false;                    // :264
                     event += (int)got;
                     if (!status) { done = true; break; }                                // :186-189
@@ -163,6 +169,7 @@ bool Coach::run() {
                 }
                 if (m_printLevel > 2) INFO("    Event %d (cost: %7.3f)", event, m_wavenet->lastCost());
             }
+            if (!m_wavenet->sync()) done = true;                                        // outstanding logs; a rejected batch ends the initialisation (:186-189)
         }
         m_wavenet->costLog().pop_back();                                                // :274
         if (m_saveSnapshots) m_wavenet->save(snap++);                                   // :277

@@ -146,6 +146,7 @@ bool Wavenet::setFilter(const Col& filter) {
         WARNING("Input filter has %d coefficients; at most %d are supported.", (int)filter.n_elem, WN_MAX_TAPS);
         return false;
     }
+    if (m_pending) fetchUpdates_();      // outstanding updates belong before this entry of the filter log
     m_filter = filter;
     m_filterLog.push_back(m_filter);
     if (m_momentum.n_elem != m_filter.n_elem) m_momentum.zeros(m_filter.n_elem);
@@ -155,6 +156,7 @@ bool Wavenet::setFilter(const Col& filter) {
 
 bool Wavenet::setMomentum(const Col& momentum) {
     assert(momentum.size() == m_filter.size());
+    if (m_pending) fetchUpdates_();
     m_momentum = momentum;
     return onReplicas_([&](DeviceSession& d) { return !d.ctx || d.ok(wn_set_momentum(d.ctx, m_momentum.memptr(), (int)m_momentum.n_elem)); });
 }
@@ -273,6 +275,7 @@ bool Wavenet::trainBatch(const double* X, unsigned B, unsigned nRows, unsigned n
     if (B == 0) return true;
     DeviceSession& dev = device_();
     if (!dev.ctx) return false;
+    if (!fetchUpdates_()) return false;
     const std::size_t n = (std::size_t)nRows * nCols;
     unsigned done = 0;
     if (!m_replicas.empty() && m_batchQueue.empty() && B >= m_batchSize) {
@@ -293,13 +296,14 @@ bool Wavenet::trainBatch(const double* X, unsigned B, unsigned nRows, unsigned n
     return trainOnDevice_(dX, B - done, nRows, nCols, lambdas ? lambdas + done : nullptr);
 }
 
-bool Wavenet::trainBatchFrom(GeneratorBase& generator, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas) {
+bool Wavenet::trainBatchFrom(GeneratorBase& generator, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas, bool deferLogs) {
     if (!generator.hasDeviceForm() || !checkShape_(nRows, nCols)) return false;
     if (B == 0) return true;
     DeviceSession& dev = device_();
     if (!dev.ctx) return false;
     unsigned done = 0;
     if (!m_replicas.empty() && m_batchQueue.empty() && B >= m_batchSize) {
+        if (!fetchUpdates_()) return false;
         // every replica's share is generated where it is trained; the shares are taken in the order of the examples,
         // so the generator's sequence is the one a single device would see
         auto place = [&](unsigned r, double* dst, unsigned, unsigned count) {
@@ -313,9 +317,14 @@ bool Wavenet::trainBatchFrom(GeneratorBase& generator, unsigned B, unsigned nRow
         }
         if (done == B) return true;
     }
+    // examples that already sit in the generator's own device memory are trained where they are
+    const double* span = m_replicas.empty() ? generator.deviceSpan(dev.ctx, B - done) : nullptr;
+    if (span) return trainOnDevice_(span, B - done, nRows, nCols, lambdas ? lambdas + done : nullptr, deferLogs);
+    // (batches still queued may read this buffer: the generator writes it on the same stream, behind them, and a
+    // reallocation waits for the device)
     double* dX = dev.buf(DeviceSession::X, (std::size_t)(B - done) * nRows * nCols);
     if (!dX || !generator.nextOnDevice(dev.ctx, dX, B - done)) return false;
-    return trainOnDevice_(dX, B - done, nRows, nCols, lambdas ? lambdas + done : nullptr);
+    return trainOnDevice_(dX, B - done, nRows, nCols, lambdas ? lambdas + done : nullptr, deferLogs);
 }
 
 // Contiguous share [begin, end) of `total` examples for replica r of G; sizes differ by at most one.
@@ -374,8 +383,8 @@ bool Wavenet::trainSharded_(Place place, unsigned nb, unsigned first, unsigned n
                 return false;
         }
     }
-    int firstLog = 0;
-    if (wn_num_updates(dev.ctx, &firstLog) == WN_ERR_NONFINITE) return diverged_();
+    if (!deviceSteps_()) return false;
+    const int firstLog = m_devSteps;
     for (unsigned b = 0; b < nb; b++) {
         double lambdaSum = 0;
         for (unsigned e = 0; e < m_batchSize; e++) lambdaSum += lambdas ? lambdas[first + b * m_batchSize + e] : m_lambda;
@@ -390,75 +399,101 @@ bool Wavenet::trainSharded_(Place place, unsigned nb, unsigned first, unsigned n
         if (!onReplicas_([&](DeviceSession& d) { return d.ok(wn_apply_update(d.ctx, (double)m_batchSize, lambdaSum, m_alpha, inertia, m_wavelet)); }))
             return false;
     }
-    // every replica holds the same state: the logs come from the first
+    // every replica holds the same state: the logs, the momentum and the verdict come from the first, in one readback
+    std::vector<double> F((std::size_t)nb * N), C(nb);
     int lastLog = 0;
-    const int state = wn_num_updates(dev.ctx, &lastLog);
+    const int state = wn_get_updates(dev.ctx, firstLog, (int)nb, &lastLog, F.data(), C.data(), m_momentum.memptr());
     if (state != WN_OK && state != WN_ERR_NONFINITE) return dev.ok(state);
-    const unsigned applied = (unsigned)(lastLog - firstLog);
-    std::vector<double> F((std::size_t)applied * N), C(applied);
-    if (applied && !dev.ok(wn_get_logs(dev.ctx, firstLog, (int)applied, F.data(), C.data()))) return false;
+    const unsigned applied = (unsigned)std::min<int>((int)nb, std::max(0, lastLog - firstLog));
+    m_devSteps = lastLog;
     for (unsigned b = 0; b < applied; b++) {
         m_filterLog.push_back(Col(N, F.data() + (std::size_t)b * N));
         m_costLog.back() = C[b];
         m_costLog.push_back(0);
     }
     if (applied) m_filter = m_filterLog.back();
-    int nn = N;
-    if (!dev.ok(wn_get_momentum(dev.ctx, m_momentum.memptr(), &nn))) return false;
     if (lambdas && applied) m_lambda = lambdas[first + applied * m_batchSize - 1];
     if (state == WN_ERR_NONFINITE) return diverged_();
     return true;
 }
 
+// The device's update counter, kept on the host between fetches (one readback the first time).
+bool Wavenet::deviceSteps_() {
+    if (m_devSteps >= 0) return true;
+    DeviceSession& dev = device_();
+    int steps = 0;
+    const int state = wn_num_updates(dev.ctx, &steps);
+    if (state == WN_ERR_NONFINITE) return diverged_();
+    if (!dev.ok(state)) return false;
+    m_devSteps = steps;
+    return true;
+}
+
+// The logs of the updates queued since the last fetch, the momentum, and whether a batch was refused: one readback.
+// A batch with non-finite sums was not applied, nor was any batch after it.
+bool Wavenet::fetchUpdates_() {
+    if (!m_pending) return true;
+    DeviceSession& dev = device_();
+    const int N = (int)m_filter.n_elem;
+    std::vector<double> F((std::size_t)m_pending * N), C(m_pending);
+    int steps = 0;
+    if (m_momentum.n_elem != m_filter.n_elem) m_momentum.zeros(m_filter.n_elem);
+    const int state = wn_get_updates(dev.ctx, m_devSteps, (int)m_pending, &steps, F.data(), C.data(), m_momentum.memptr());
+    if (state != WN_OK && state != WN_ERR_NONFINITE) { m_pending = 0; m_pendingLambda.clear(); return dev.ok(state); }
+    const unsigned applied = (unsigned)std::min<int>((int)m_pending, std::max(0, steps - m_devSteps));
+    for (unsigned b = 0; b < applied; b++) {
+        m_filterLog.push_back(Col(N, F.data() + (std::size_t)b * N));
+        m_costLog.back() = C[b];
+        m_costLog.push_back(0);
+    }
+    if (applied) {
+        m_filter = m_filterLog.back();
+        const double l = m_pendingLambda[applied - 1];
+        if (l == l) m_lambda = l;
+    }
+    m_devSteps = steps;
+    m_pending = 0;
+    m_pendingLambda.clear();
+    if (state == WN_ERR_NONFINITE) return diverged_();                                  // :234-241
+    // batches that ran on the first device alone (a pending queue came first): the replicas follow
+    for (DeviceSession* r : m_replicas) {
+        if (!r->ok(wn_set_filter(r->ctx, m_filter.memptr(), N)) || !r->ok(wn_set_momentum(r->ctx, m_momentum.memptr(), N))) return false;
+    }
+    return true;
+}
+
+bool Wavenet::sync() { return fetchUpdates_(); }
+
 // B examples already on the device: whole batches back to back, the rest through the batch queue.
-bool Wavenet::trainOnDevice_(const double* dX, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas) {
+bool Wavenet::trainOnDevice_(const double* dX, unsigned B, unsigned nRows, unsigned nCols, const double* lambdas, bool deferLogs) {
     DeviceSession& dev = device_();
     const std::size_t n = (std::size_t)nRows * nCols;
-    const int N = (int)m_filter.n_elem;
     unsigned done = 0;
     while (done < B) {
         const unsigned room = m_batchSize > m_batchQueue.size() ? m_batchSize - (unsigned)m_batchQueue.size() : 1;
         if (m_batchQueue.empty() && B - done >= m_batchSize && m_batchSize >= 1) {
             // whole batches back to back on the device: train kernel, batch reduction, update kernel
-            // (at most 8192 per round trip: the device keeps the last 16384 log entries)
-            const unsigned nb = std::min((B - done) / m_batchSize, 8192u);
-            int firstLog = 0;
-            if (wn_num_updates(dev.ctx, &firstLog) == WN_ERR_NONFINITE) return diverged_();
+            // (at most 8192 outstanding: the device keeps the last 16384 log entries)
+            if (m_pending >= 8192u && !fetchUpdates_()) return false;
+            if (!deviceSteps_()) return false;
+            const unsigned nb = std::min((B - done) / m_batchSize, 8192u - m_pending);
             for (unsigned b = 0; b < nb; b++) {
                 const double* Xb = dX + (std::size_t)(done + b * m_batchSize) * n;
                 double lambdaSum = 0;
                 for (unsigned e = 0; e < m_batchSize; e++)
                     lambdaSum += lambdas ? lambdas[done + b * m_batchSize + e] : m_lambda;
-                const unsigned steps = (unsigned)m_costLog.size() - 1 + b;
+                const unsigned steps = (unsigned)m_costLog.size() - 1 + m_pending;
                 if (!dev.ok(wn_train_step(dev.ctx, Xb, (int)m_batchSize, (int)nRows, (int)nCols, (double)m_batchSize, lambdaSum, m_alpha,
                                           effectiveInertia_(steps), m_wavelet)))
                     return false;
-            }
-            // bring the logs and the state back; a batch with non-finite sums was not applied, nor was any
-            // batch after it
-            int lastLog = 0;
-            const int state = wn_num_updates(dev.ctx, &lastLog);
-            if (state != WN_OK && state != WN_ERR_NONFINITE) return dev.ok(state);
-            const unsigned applied = (unsigned)(lastLog - firstLog);
-            std::vector<double> F((std::size_t)applied * N), C(applied);
-            if (applied && !dev.ok(wn_get_logs(dev.ctx, firstLog, (int)applied, F.data(), C.data()))) return false;
-            for (unsigned b = 0; b < applied; b++) {
-                m_filterLog.push_back(Col(N, F.data() + (std::size_t)b * N));
-                m_costLog.back() = C[b];
-                m_costLog.push_back(0);
-            }
-            if (applied) m_filter = m_filterLog.back();
-            int nn = N;
-            if (!dev.ok(wn_get_momentum(dev.ctx, m_momentum.memptr(), &nn))) return false;
-            if (lambdas && applied) m_lambda = lambdas[done + applied * m_batchSize - 1];
-            if (state == WN_ERR_NONFINITE) return diverged_();                          // :234-241
-            // batches that ran on the first device alone (a pending queue came first): the replicas follow
-            for (DeviceSession* r : m_replicas) {
-                if (!r->ok(wn_set_filter(r->ctx, m_filter.memptr(), N)) || !r->ok(wn_set_momentum(r->ctx, m_momentum.memptr(), N))) return false;
+                m_pending++;
+                m_pendingLambda.push_back(lambdas ? lambdas[done + (b + 1) * m_batchSize - 1] : std::nan(""));
             }
             done += nb * m_batchSize;
+            if (!deferLogs && !fetchUpdates_()) return false;
         } else {
             // fill the pending batch (or a trailing partial one) example by example
+            if (!fetchUpdates_()) return false;
             const unsigned count = std::min(room, B - done);
             if (!queueExamples_(dX + (std::size_t)done * n, count, nRows, nCols, lambdas ? lambdas + done : nullptr)) return false;
             done += count;
@@ -476,6 +511,8 @@ bool Wavenet::diverged_() const {
 }
 
 void Wavenet::clear() {
+    if (m_pending) fetchUpdates_();       // (waits for what is queued; the logs are dropped below)
+    m_devSteps = m_session ? 0 : -1;      // wn_clear_logs restarts the device's update counter
     scaleMomentum_(0.);
     clearFilterLog();
     clearCostLog();
