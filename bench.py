@@ -32,10 +32,14 @@ WORKLOADS = {
     "2d64n16": (64, 64, 4096, 16, "calorimeter", 6.0),
     "1d1024": (1024, 1, 4096, 16, "bumps", 6.0),
     "2d512": (512, 512, 2048, 4, "calorimeter", 8.0),    # streamed path; 16384 images over 8 GPUs
+    "2d512n16": (512, 512, 2048, 16, "calorimeter", 5.0),
     "1d1m": (1 << 20, 1, 8, 32, "bumps", 6.0),           # streamed path, 8 signals per GPU
 }
 HEADLINE = "2d64"
-ALL_ORDER = ["2d64n16", "1d1024", "2d512", "1d1m", HEADLINE]
+ALL_ORDER = ["2d64n16", "1d1024", "2d512", "2d512n16", "1d1m", HEADLINE]
+# Distinct resident batches the timed steps rotate over, so that more than the 256 MiB Infinity Cache lies between two
+# uses of an input (64x64: 3 x 134 MB); a batch of 512x512 images (4.3 GB) is beyond it by itself.
+ROTATE = {"2d64": 3, "2d64n16": 3, "1d1024": 10, "2d512": 1, "2d512n16": 1, "1d1m": 6}
 
 # What actually limits the dominant kernel (the graded roofline fraction prices the step in the bytes an
 # unfused pipeline would move; these kernels keep most of those passes on chip).
@@ -44,6 +48,7 @@ LIMITER = {
     "2d64n16": "VALU issue (filter cascade and sort) with one wave per SIMD",
     "1d1024": "VALU issue: the Gini phase (sort and ranks) is most of the kernel's instructions",
     "2d512": "HBM passes of the per-example ranking and of the four line-transform kernels",
+    "2d512n16": "the level-by-level row pass of 16-tap filters (L1 / LDS requests) and the ranking",
     "1d1m": "kernel count and tail latency: 8 signals per step give each launch little work",
 }
 
@@ -102,6 +107,78 @@ def cpu_baseline(X, a0, lam, alpha, budget_s):
                       f"(matrix operators rebuilt per update, plain loops instead of BLAS), {dt:.1f} s"}
 
 
+def exchange_probe(ctx, dX, B, R, C, lam, alpha, steps, fused_ms):
+    """Times wn_train_batch + one-rank wn_allreduce_sums + wn_apply_update per step against the fused wn_train_step
+    (fused_ms), on one GPU.  The difference is the cost of splitting the step around the collective -- what stays
+    on the serial path of every batch when the sums have to travel -- and bounds the weak-scaling efficiency."""
+    import torch
+    # (RCCL prints a version banner on standard output when it starts: sent to standard error, the JSON lines stay alone)
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        ctx.comm_init(ctx.comm_unique_id(), 1, 0)
+    except Exception as exc:  # no RCCL on this box: say so instead of failing the bench
+        return {"error": str(exc)}
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def one():
+        ctx.train_batch(dX, B, R, C)
+        ctx.allreduce_sums()
+        ctx.apply_update(B, lam * B, alpha, 0.0, True)
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        one()
+    ev1.record()
+    torch.cuda.synchronize()
+    wall_ms = 1e3 * (time.perf_counter() - t0) / steps
+    split_ms = ev0.elapsed_time(ev1) / steps
+    over_us = 1e3 * (max(split_ms, wall_ms) - fused_ms)
+    return {"split_step_ms_device": split_ms, "split_step_ms_wall": wall_ms, "fused_step_ms": fused_ms,
+            "exchange_overhead_us": over_us,
+            "implied_weak_scaling_bound": fused_ms / max(split_ms, wall_ms, fused_ms),
+            "note": "one-rank RCCL all-reduce of N+2 doubles between wn_train_batch and wn_apply_update on one GPU; "
+                    "with more ranks the collective's latency over xGMI comes on top"}
+
+
+def coach_cpp_probe(R, C, N, B, a0):
+    """Coach::run of the C++ host layer (tests/cpp/host_driver bench), as a child process: the reference's own
+    training entry point (src/Coach.cxx:71-296) on a device-resident set of 8 batches, 6 epochs, and on batches drawn
+    from the on-device generator; and the reference's usual regime of batch 8 with the adaptive learning rate."""
+    import subprocess
+    import tempfile
+    driver = os.path.join(ROOT, "tests", "cpp", "host_driver")
+    if not os.path.exists(driver):
+        return {"error": "tests/cpp/host_driver not built"}
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        np.asarray(a0, dtype=np.float64).tofile(f)
+        path = f.name
+    out = {}
+    try:
+        for key, cfg in (("resident_batch%d" % B, [B, 8 * B, 6, 0, "resident"]),
+                         ("generated_batch%d" % B, [B, 8 * B, 6, 0, "generated"]),
+                         ("adaptive_batch8", [8, 4096, 4, 1, "resident"])):
+            cmd = [driver, "bench", R, C, N] + cfg + ["calorimeter", path]
+            res = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, timeout=300)
+            if res.returncode != 0:
+                out[key] = {"error": res.stderr[-300:]}
+                continue
+            line = json.loads(res.stdout.strip().splitlines()[-1])
+            out[key] = {"examples_per_s": line["coach_run_examples_per_s"], "updates": line["updates"],
+                        "events_per_epoch": line["events_per_epoch"], "epochs": line["epochs"]}
+    finally:
+        os.unlink(path)
+    return out
+
+
 def load_traffic(workload):
     """HBM bytes per step from the committed rocprofv3 PMC passes (profiles/traffic.json), if present."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
@@ -138,15 +215,24 @@ def run_workload(name, args, rank, local_rank, world, dist):
     ctx = Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
     X = None
     seed = 1000
-    if gen == "calorimeter":
-        # generated on the device (bit-identical to generators.calorimeter; tests/test_gpu_generators.py);
-        # example numbers continue across ranks, so the ranks hold disjoint parts of one sequence
-        dX = torch.empty(max(B, 1) * R * C, dtype=torch.float64, device="cuda")
-        for e0 in range(0, B, 32768):
-            ctx.generate_calorimeter(dX[e0 * R * C:], min(32768, B - e0), R, C, seed=seed, first=first + e0)
-    else:
-        X = make_inputs(gen, first + B, R, C, seed=seed)[first:]
-        dX = torch.from_numpy(to_device_layout(X)).cuda()
+    nrot = max(1, args.rotate if args.rotate else ROTATE.get(name, 1))
+    batches = []
+    for k in range(nrot):
+        # batch k of the rotation continues the sequence of examples behind the ranks' shares of batch k - 1
+        firstk = first + k * global_batch
+        if gen == "calorimeter":
+            # generated on the device (bit-identical to generators.calorimeter; tests/test_gpu_generators.py);
+            # example numbers continue across ranks, so the ranks hold disjoint parts of one sequence
+            dXk = torch.empty(max(B, 1) * R * C, dtype=torch.float64, device="cuda")
+            for e0 in range(0, B, 32768):
+                ctx.generate_calorimeter(dXk[e0 * R * C:], min(32768, B - e0), R, C, seed=seed, first=firstk + e0)
+        else:
+            Xk = make_inputs(gen, firstk + B, R, C, seed=seed)[firstk:]
+            if k == 0:
+                X = Xk
+            dXk = torch.from_numpy(to_device_layout(Xk)).cuda()
+        batches.append(dXk)
+    dX = batches[0]
     ctx.set_filter(a0)
     trainer = DataParallelTrainer(ctx, world)
 
@@ -155,29 +241,41 @@ def run_workload(name, args, rank, local_rank, world, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.step(dX, B, R, C, lam, alpha, B_total=global_batch)
+    def timed(steps, rotate):
+        """(wall seconds, device ms per step) of `steps` steps bracketed by barrier + synchronize."""
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync_all()
+        t0 = time.perf_counter()
+        ev0.record()
+        for i in range(steps):
+            trainer.step(batches[i % nrot] if rotate else dX, B, R, C, lam, alpha, B_total=global_batch)
+        ev1.record()
+        torch.cuda.synchronize()
+        sync_all()
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1) / steps
+
+    for i in range(args.warmup):
+        trainer.step(batches[i % nrot], B, R, C, lam, alpha, B_total=global_batch)
     # device time of the timed region: a pair of events on the stream the kernels are launched on (the
     # context runs on torch's current stream)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    sync_all()
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        trainer.step(dX, B, R, C, lam, alpha, B_total=global_batch)
-    ev1.record()
-    torch.cuda.synchronize()
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    elapsed, device_ms = timed(args.steps, True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    device_ms = ev0.elapsed_time(ev1) / args.steps      # per step: one launch of the fused kernels
+    final_filter = ctx.filter()
+    # the same number of steps on ONE resident batch, which the Infinity Cache can hold on to: does the time move?
+    single_ms = None
+    if nrot > 1 and world == 1:
+        single_ms = timed(args.steps, False)[1]
+    # What every rank of a multi-GPU run pays on the serial path of a batch, measured on this one GPU: the step as
+    # three submissions with a one-rank RCCL all-reduce of the sums in the middle against the fused single submission.
+    exchange = None
+    if world == 1 and name == HEADLINE and not args.no_exchange_probe:
+        exchange = exchange_probe(ctx, dX, B, R, C, lam, alpha, args.steps, device_ms)
 
     sums = trainer.sums()
     nonfinite = float(sums[-1])
-    final_filter = ctx.filter()
 
     out = None
     if rank == 0:
@@ -207,15 +305,23 @@ def run_workload(name, args, rank, local_rank, world, dist):
                          "limiter": LIMITER.get(name)},
             "nonfinite": nonfinite,
             "final_filter": [float(v) for v in final_filter],
+            "resident_batches_rotated": nrot,
+            "resident_bytes": nrot * B * R * C * 8,
         }
+        if single_ms is not None:
+            out["ms_per_step_one_resident_batch"] = single_ms
+        if exchange is not None:
+            out["exchange_overhead"] = exchange
         if world == 1 and not args.no_cpu_baseline:
             if X is None:
                 # the same sequence of examples, on the host: no more of them than the sample can use
                 X = make_inputs(gen, min(B, 4096, max(4, (1 << 23) // (R * C))), R, C, seed=seed)
             out["cpu_baseline"] = cpu_baseline(X, a0, lam, alpha, cpu_budget * args.cpu_scale)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if world == 1 and name == HEADLINE and not args.no_coach_probe:
+            out["coach_cpp"] = coach_cpp_probe(R, C, N, B, a0)
     ctx.close()
-    del dX
+    del dX, batches
     torch.cuda.empty_cache()
     return out
 
@@ -240,6 +346,9 @@ def main():
     ap.add_argument("--taps", type=int, default=0, help="filter length N (default: per workload)")
     ap.add_argument("--batch", type=int, default=0, help="examples per GPU per step (weak) / in all (strong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rotate", type=int, default=0, help="distinct resident batches the steps rotate over (default: per workload)")
+    ap.add_argument("--no-exchange-probe", action="store_true", help="skip the split-step / one-rank all-reduce timing of the headline")
+    ap.add_argument("--no-coach-probe", action="store_true", help="skip the C++ Coach::run timing of the headline")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="scales the seconds spent on the CPU baselines")
     ap.add_argument("--dry-run", action="store_true", help="print what each rank would run (no GPU is touched)")
     args = ap.parse_args()
