@@ -158,9 +158,14 @@ int wn_train_batch(wn_context* ctx, const double* X_dev, int B, int R, int C,
  * B; a larger example is refused with WN_ERR_UNSUPPORTED (its path needs a workspace that grows with the
  * batch).  The call makes no hipMalloc / hipFree and nothing else that allocates device memory; the first
  * call for a shape and filter length also queries that kernel's occupancy, so make one call before a
- * capture.  All calls on one GPU share the array (whatever context or stream they come through): calls
- * that overlap in time on one GPU race; calls on one stream, or otherwise ordered, do not.  Nothing in
- * the array has to be zero beforehand (every slot that is read was written by the same call).
+ * capture.  All calls on one GPU share the array (whatever context or stream they come through).  Calls
+ * through one context are ordered by its stream.  A call through another context of the same GPU first
+ * makes its stream wait (hipStreamWaitEvent on an event made in wn_create; no allocation) for the last
+ * call that used the array, and a mutex orders host threads, so calls issued through this entry point
+ * never overlap on the array.  What remains the caller's: a context whose stream is being captured must
+ * be the only one calling on that GPU during the capture, and replays of a captured graph are ordered
+ * against other calls by the caller.  Nothing in the array has to be zero beforehand (every slot that is
+ * read was written by the same call).
  */
 #define WN_STATIC_SLOTS 8192
 int wn_train_batch_static(wn_context* ctx, const double* X_dev, int B, int R, int C, double* sums_dev);

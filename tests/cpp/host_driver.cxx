@@ -26,6 +26,17 @@ static std::vector<double> readAll(const char* path) {
     return v;
 }
 
+static std::vector<int> deviceList(const char* text) {   // "0,1,3" -> {0, 1, 3}
+    std::vector<int> out;
+    for (const char* p = text; *p;) {
+        char* end = nullptr;
+        out.push_back((int)std::strtol(p, &end, 10));
+        if (end == p) break;
+        p = (*end == ',') ? end + 1 : end;
+    }
+    return out;
+}
+
 static std::string g_prefix;   // prepended to every dumped name
 static void dump(const char* name, const double* p, size_t n) {
     std::printf("%s%s %zu", g_prefix.c_str(), name, n);
@@ -115,6 +126,7 @@ int main(int argc, char** argv) {
         if (inertia > 0) w.setInertia(inertia);
         if (timeScale > 0) w.setInertiaTimeScale(timeScale);
         if (const char* rep = std::getenv("WAVENET_TEST_REPLICAS")) w.setDevices(std::vector<int>((size_t)std::atoi(rep), 0), false);
+        if (const char* devs = std::getenv("WAVENET_TEST_DEVICES")) w.setDevices(deviceList(devs), std::getenv("WAVENET_TEST_RCCL") != nullptr);
         if (!w.setFilter(Col(N, in.data()))) return 3;
         if (batched) {
             // an odd split exercises the pending-queue path between device rounds
@@ -216,6 +228,10 @@ int main(int argc, char** argv) {
         if (const char* rep = std::getenv("WAVENET_TEST_REPLICAS")) {
             // that many shares of every batch, all on GPU 0, their sums added on the host in replica order
             coach.setDevices(std::vector<int>((size_t)std::atoi(rep), 0), false);
+        }
+        if (const char* devs = std::getenv("WAVENET_TEST_DEVICES")) {
+            // one share per listed GPU ("0,1"); sums through RCCL when WAVENET_TEST_RCCL is set, else added on the host
+            coach.setDevices(deviceList(devs), std::getenv("WAVENET_TEST_RCCL") != nullptr);
         }
         if (const char* al = std::getenv("WAVENET_TEST_ALPHA")) w.setAlpha(std::atof(al));
         if (std::getenv("WAVENET_TEST_HOST_GENERATE")) coach.setGenerateOnDevice(false);

@@ -83,6 +83,38 @@ def test_trainer_through_a_nccl_group_of_one_rank():
             dist.destroy_process_group()
 
 
+def test_trainer_follows_torchs_current_stream():
+    """A step() issued under `torch.cuda.stream(s)` runs the context's kernels on `s`, the stream the
+    all-reduce would be ordered on: the trainer rebinds the context when the current stream has changed."""
+    import torch
+    from wavenet_amd import Context
+    from wavenet_amd.parallel import DataParallelTrainer
+    X = _inputs(B=8)
+    B, R, C = X.shape
+    a = F.perturbed(F.daubechies(4), 1e-2, 2)
+    dX = to_dev(X)
+    ctx, ref = Context(0), Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    side = torch.cuda.Stream()
+    try:
+        ctx.set_filter(a)
+        ref.set_filter(a)
+        tr = DataParallelTrainer(ctx, 1)
+        assert tr._stream == torch.cuda.current_stream().cuda_stream
+        tr.step(dX, B, R, C, 10.0, 1e-3)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            tr.step(dX, B, R, C, 10.0, 1e-3)
+            assert tr._stream == side.cuda_stream
+        tr.step(dX, B, R, C, 10.0, 1e-3)          # back on the first stream; wn_set_stream waits for `side`
+        assert tr._stream == torch.cuda.current_stream().cuda_stream
+        for _ in range(3):
+            ref.train_step(dX, B, R, C, B, 10.0 * B, 1e-3, 0.0, True)
+        assert np.array_equal(ctx.filter(), ref.filter())
+    finally:
+        ctx.close()
+        ref.close()
+
+
 def test_single_process_communicators_of_one_gpu():
     """wn_comm_init_all / wn_allreduce_sums_all (one host thread driving every GPU, as the host layer's data-parallel
     Coach does) with the one GPU there is: the grouped all-reduce returns the sums unchanged, wn_train_step on a

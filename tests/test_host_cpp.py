@@ -171,6 +171,33 @@ def test_data_parallel_coach_is_shard_invariant(oracle, flags, events, batch):
         assert np.allclose(cl, w.cost_log(), rtol=1e-9, atol=1e-15)
 
 
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()      # counting devices does not initialise the GPU
+
+
+@pytest.mark.parametrize("batch,flags", [(8, 0), (6, 3)])
+def test_two_gpus_through_rccl_equal_the_host_sums(batch, flags):
+    """The data-parallel Coach on GPUs 0 and 1 with the sums exchanged by RCCL (wn_comm_init_all, grouped
+    wn_allreduce_sums_all from the one host thread) against the same run with the sums added on the host, and
+    against one GPU alone: the filter log agrees to the rounding of a re-ordered sum.  Skipped on a box with
+    one GPU: until a box with two has run it, the RCCL branch with more than one rank is unverified."""
+    if _gpu_count() < 2:
+        pytest.skip("needs two GPUs")
+    R, C, N, seed, events = 16, 16, 4, 42, 96
+    a = F.perturbed(F.DB4, 5e-2, 5)
+    base, _ = run_driver(["coach", R, C, N, events, 1, batch, flags, seed, -1], [a])
+    host, _ = run_driver(["coach", R, C, N, events, 1, batch, flags, seed, -1], [a], env={"WAVENET_TEST_DEVICES": "0,1"})
+    rccl, _ = run_driver(["coach", R, C, N, events, 1, batch, flags, seed, -1], [a],
+                         env={"WAVENET_TEST_DEVICES": "0,1", "WAVENET_TEST_RCCL": "1"})
+    for out in (host, rccl):
+        assert out["filterLog"].shape == base["filterLog"].shape
+        assert np.allclose(out["filterLog"], base["filterLog"], rtol=1e-12, atol=0)
+        assert np.allclose(out["costLog"], base["costLog"], rtol=1e-12, atol=1e-15)
+        assert np.array_equal(out["misc"], base["misc"])
+    assert np.allclose(rccl["filterLog"], host["filterLog"], rtol=1e-12, atol=0)
+
+
 @pytest.mark.parametrize("replicas", [2, 3])
 def test_data_parallel_train_batch_with_a_pending_queue(oracle, replicas):
     """trainBatch in two calls that do not end on batch boundaries: whole batches go over the replicas, the

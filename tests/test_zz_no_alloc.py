@@ -51,3 +51,38 @@ def test_static_entry_point_refuses_streamed_shapes():
         ctx.train_batch_static(dX, 1, 128, 64, out)
     assert err.value.status == WN_ERR_UNSUPPORTED and "8192 samples exceed the 4096" in str(err.value)
     ctx.close()
+
+
+def test_static_calls_of_two_contexts_on_two_streams_do_not_overlap():
+    """Two contexts of one GPU, each on a stream of its own, share the GPU's one array.  Calls issued one after
+    the other through the entry point are ordered by the library (the second stream waits for the event the
+    first call recorded), so alternating calls without any synchronisation in between still give each context
+    the sums wn_train_batch gives it."""
+    import torch
+    from wavenet_amd import Context
+    R, C, N = 64, 64, 4
+    rng = np.random.default_rng(8)
+    shapes = [(3000, 1), (2500, 2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ctxs, Xs, outs, wants = [], [], [], []
+    for (B, seed), st in zip(shapes, streams):
+        ctx = Context(0, stream=st.cuda_stream)
+        ctx.set_filter(F.perturbed(F.daubechies(N), 1e-2, seed))
+        X = np.where(rng.random((B, R, C)) < 0.7, 0.0, rng.random((B, R, C)))
+        dX = to_dev(X)
+        torch.cuda.synchronize()
+        ctx.train_batch(dX, B, R, C)
+        wants.append(ctx.sums().copy())
+        ctxs.append(ctx)
+        Xs.append(dX)
+        outs.append([torch.full((N + 2,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(8)])
+    torch.cuda.synchronize()
+    for rep in range(8):
+        for k in (0, 1):
+            ctxs[k].train_batch_static(Xs[k], shapes[k][0], R, C, outs[k][rep])
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        for rep in range(8):
+            assert np.array_equal(outs[k][rep].cpu().numpy(), wants[k]), (k, rep)
+    for ctx in ctxs:
+        ctx.close()

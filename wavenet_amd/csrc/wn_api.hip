@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -47,10 +48,16 @@ const int kLogCap = 16384;
 // for callers that cannot allocate.  Every GPU the library runs on holds its own copy at its own address;
 // scratch_ptr[device] is that address, looked up once per device in wn_create.  In host code the array's
 // name is only a handle for that look-up, never a device address.
+// Every context of a GPU shares that GPU's array.  scratch_last[device] is the context whose call used it
+// last; a call from another context first makes its stream wait for that context's static_done event, so
+// that calls issued one after the other never overlap on the array whatever streams they run on.
+// scratch_mutex guards the look-up, scratch_last and the wait/launch/record sequence against host threads.
 constexpr int kStaticSlots = WN_STATIC_SLOTS;
 static __device__ __align__(256) double scratch[(size_t)kStaticSlots * wn::PSTRIDE];
 constexpr int kMaxDevices = 64;
+static std::mutex scratch_mutex;
 static double* scratch_ptr[kMaxDevices];
+static wn_context* scratch_last[kMaxDevices];
 
 namespace {
 
@@ -276,15 +283,24 @@ int wn_create(int device, wn_context** out) {
         delete ctx;
         return WN_ERR_ARG;
     }
-    if (!scratch_ptr[device]) {   // this device is current: the address is the one of its copy
-        double* p = nullptr;
-        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
-        if (e != hipSuccess || !p) {
-            wn::global_error() = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
-            delete ctx;
-            return WN_ERR_HIP;
+    {
+        std::lock_guard<std::mutex> lock(scratch_mutex);
+        if (!scratch_ptr[device]) {   // this device is current: the address is the one of its copy
+            double* p = nullptr;
+            e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !p) {
+                wn::global_error() = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+                delete ctx;
+                return WN_ERR_HIP;
+            }
+            scratch_ptr[device] = p;
         }
-        scratch_ptr[device] = p;
+    }
+    e = hipEventCreateWithFlags(&ctx->static_done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        wn::global_error() = std::string("hipEventCreateWithFlags: ") + hipGetErrorString(e);
+        delete ctx;
+        return WN_ERR_HIP;
     }
     int rc = WN_OK;
     auto alloc = [&](void** p, size_t bytes) {
@@ -322,6 +338,11 @@ int wn_destroy(wn_context* ctx) {
     (void)hipSetDevice(ctx->device);
     wn_comm_destroy(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->device >= 0 && ctx->device < kMaxDevices) {
+        std::lock_guard<std::mutex> lock(scratch_mutex);
+        if (scratch_last[ctx->device] == ctx) scratch_last[ctx->device] = nullptr;  // its calls have finished
+    }
+    if (ctx->static_done) (void)hipEventDestroy(ctx->static_done);
     (void)hipFree(ctx->dfilt);
     (void)hipFree(ctx->partial);
     (void)hipFree(ctx->own_sums);
@@ -771,9 +792,17 @@ int wn_train_batch_static(wn_context* ctx, const double* X, int B, int R, int C,
         return fail(ctx, WN_ERR_UNSUPPORTED,
                     "wn_train_batch_static: examples of " + std::to_string((long long)R * C) + " samples exceed the " +
                         std::to_string(WN_MAX_FUSED) + " it takes (larger ones need a workspace that grows with the batch: use wn_train_batch)");
+    std::lock_guard<std::mutex> lock(scratch_mutex);
     double* part = scratch_ptr[ctx->device];
     if (!part) return fail(ctx, WN_ERR_STATE, "the static scratch array was not located on this device");
-    return train_fused(ctx, X, B, lgR, lgC, sc, nullptr, nullptr, part, kStaticSlots, sums_dev);
+    wn_context* last = scratch_last[ctx->device];
+    if (last && last != ctx) WN_HIP(ctx, hipStreamWaitEvent(ctx->stream, last->static_done, 0));
+    rc = train_fused(ctx, X, B, lgR, lgC, sc, nullptr, nullptr, part, kStaticSlots, sums_dev);
+    if (rc == WN_OK && B > 0) {
+        WN_HIP(ctx, hipEventRecord(ctx->static_done, ctx->stream));
+        scratch_last[ctx->device] = ctx;
+    }
+    return rc;
 }
 
 int wn_sums(wn_context* ctx, double** sums_dev, int* count) {

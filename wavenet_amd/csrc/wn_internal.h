@@ -41,6 +41,7 @@ struct wn_context {
     // (an event on the main stream), while the main stream goes on with the backward pass
     hipStream_t side_stream = nullptr;
     hipEvent_t rank_event = nullptr;
+    hipEvent_t static_done = nullptr;   // recorded after each wn_train_batch_static of this context
     unsigned* ticket = nullptr;  // counter of finished workgroups of a training kernel whose last workgroup ends the step
     std::vector<hipEvent_t> prof_begin, prof_end;
     int prof_used = 0;

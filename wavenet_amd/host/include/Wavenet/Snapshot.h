@@ -47,6 +47,7 @@ public:
 
 protected:
     bool hasFormatSpecifier_() const { return m_pattern.find("%") != std::string::npos; }
+    void warnFixedName_(const char* what) const;
 
 private:
     std::string m_pattern = "";

@@ -21,31 +21,46 @@ wn_context* sharedContext() {
     return ctx;
 }
 
-// Runs SparseTerm / SparseTermDeriv on n values; delta may be null.  NaN on failure.
+// Device buffers of the free functions, kept from call to call and grown when a longer vector comes.
+struct SharedBuffers {
+    double *Y = nullptr, *D = nullptr, *S = nullptr;
+    std::size_t capacity = 0;
+};
+
+// Runs SparseTerm / SparseTermDeriv on n values (any radix-2 length the library takes: the streamed ranking beyond
+// WN_MAX_FUSED coefficients); delta may be null.  NaN on failure.
 double sparseOnDevice(const double* c, std::size_t n, double* delta) {
     const double nan = std::numeric_limits<double>::quiet_NaN();
+    static SharedBuffers buf;
     wn_context* ctx = sharedContext();
     if (!ctx) return nan;
-    if (!isRadix2((unsigned)n) || n > WN_MAX_FUSED) {
-        ERROR("SparseTerm on %zu coefficients is not supported (radix 2, at most %d).", n, WN_MAX_FUSED);
+    if (!isRadix2((unsigned)n) || n > ((std::size_t)1 << 30)) {
+        ERROR("SparseTerm on %zu coefficients is not supported (radix 2, at most 2^30).", n);
         return nan;
     }
-    double *dY = nullptr, *dD = nullptr, *dS = nullptr;
+    if (buf.capacity < n) {
+        if (buf.Y) wn_free(ctx, buf.Y);
+        if (buf.D) wn_free(ctx, buf.D);
+        buf.Y = buf.D = nullptr;
+        buf.capacity = 0;
+        if (wn_malloc(ctx, (void**)&buf.Y, n * sizeof(double)) != WN_OK || wn_malloc(ctx, (void**)&buf.D, n * sizeof(double)) != WN_OK) {
+            ERROR("%s", wn_last_error(ctx));
+            if (buf.Y) wn_free(ctx, buf.Y);
+            buf.Y = buf.D = nullptr;
+            return nan;
+        }
+        buf.capacity = n;
+    }
+    if (!buf.S && wn_malloc(ctx, (void**)&buf.S, sizeof(double)) != WN_OK) { buf.S = nullptr; return nan; }
     double S = nan;
-    bool ok = wn_malloc(ctx, (void**)&dY, n * sizeof(double)) == WN_OK &&
-              wn_malloc(ctx, (void**)&dD, n * sizeof(double)) == WN_OK &&
-              wn_malloc(ctx, (void**)&dS, sizeof(double)) == WN_OK;
-    ok = ok && wn_memcpy_h2d(ctx, dY, c, n * sizeof(double)) == WN_OK;
-    ok = ok && wn_sparse_term_deriv(ctx, dY, 1, (int)n, delta ? dD : nullptr, dS) == WN_OK;
-    ok = ok && wn_memcpy_d2h(ctx, &S, dS, sizeof(double)) == WN_OK;
-    if (ok && delta) ok = wn_memcpy_d2h(ctx, delta, dD, n * sizeof(double)) == WN_OK;
+    bool ok = wn_memcpy_h2d(ctx, buf.Y, c, n * sizeof(double)) == WN_OK;
+    ok = ok && wn_sparse_term_deriv(ctx, buf.Y, 1, (int)n, delta ? buf.D : nullptr, buf.S) == WN_OK;
+    ok = ok && wn_memcpy_d2h(ctx, &S, buf.S, sizeof(double)) == WN_OK;
+    if (ok && delta) ok = wn_memcpy_d2h(ctx, delta, buf.D, n * sizeof(double)) == WN_OK;
     if (!ok) {
         ERROR("%s", wn_last_error(ctx));
         S = nan;
     }
-    wn_free(ctx, dY);
-    wn_free(ctx, dD);
-    wn_free(ctx, dS);
     return S;
 }
 

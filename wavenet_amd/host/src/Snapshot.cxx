@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <fstream>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "Wavenet/Wavenet.h"
@@ -23,36 +24,22 @@ bool dirExists(const std::string& path) {
 
 std::string Snapshot::file() const {
     if (!hasFormatSpecifier_()) return m_pattern;
-    char buff[100];                                             // the reference's limit (src/Snapshot.cxx:13)
-    std::snprintf(buff, sizeof(buff), m_pattern.c_str(), m_number);
-    return std::string(buff);
+    const int len = std::snprintf(nullptr, 0, m_pattern.c_str(), m_number);
+    if (len <= 0) return m_pattern;
+    std::vector<char> text((std::size_t)len + 1);
+    std::snprintf(text.data(), text.size(), m_pattern.c_str(), m_number);
+    return std::string(text.data(), (std::size_t)len);
 }
 
-Snapshot& Snapshot::operator++() {
-    if (!hasFormatSpecifier_()) WARNING("Calling pre-fix increment operator for snapshot with no format specifiers in file name pattern");
-    ++m_number;
-    return *this;
+// Stepping the number of a snapshot whose file name has no place for it changes nothing on disk: say so once per call.
+void Snapshot::warnFixedName_(const char* what) const {
+    if (!hasFormatSpecifier_()) WARNING("The snapshot's file name '%s' holds no number: %s has no effect on it.", m_pattern.c_str(), what);
 }
 
-Snapshot& Snapshot::operator--() {
-    if (!hasFormatSpecifier_()) WARNING("Calling pre-fix decrement operator for snapshot with no format specifiers in file name pattern");
-    --m_number;
-    return *this;
-}
-
-Snapshot Snapshot::operator++(int) {
-    if (!hasFormatSpecifier_()) WARNING("Calling post-fix increment operator for snapshot with no format specifiers in file name pattern");
-    Snapshot before(*this);
-    m_number++;
-    return before;
-}
-
-Snapshot Snapshot::operator--(int) {
-    if (!hasFormatSpecifier_()) WARNING("Calling post-fix decrement operator for snapshot with no format specifiers in file name pattern");
-    Snapshot before(*this);
-    m_number--;
-    return before;
-}
+Snapshot& Snapshot::operator++() { warnFixedName_("++snapshot"); ++m_number; return *this; }
+Snapshot& Snapshot::operator--() { warnFixedName_("--snapshot"); --m_number; return *this; }
+Snapshot Snapshot::operator++(int) { warnFixedName_("snapshot++"); Snapshot before(*this); ++m_number; return before; }
+Snapshot Snapshot::operator--(int) { warnFixedName_("snapshot--"); Snapshot before(*this); --m_number; return before; }
 
 namespace {
 
@@ -104,62 +91,70 @@ Snapshot& operator<<(Snapshot& snap, const Wavenet& wavenet) {
     return snap;
 }
 
+// Reads what operator<< above and the reference's writer (src/Snapshot.cxx:54-81) produce.  The file is cut into
+// whitespace-separated tokens once; a cursor then walks through: four scalars, two vectors closed by a token that
+// holds a '#', the batch size, a section name, and three sections.  In the queue and filter-log sections a run of
+// numbers is one vector and whatever follows it closes it; a section ends at an empty run, at the next section's name
+// or at the end of the file.  The cost log is every number that is left.  The same files are accepted, and read to
+// the same values, as by the reference's reader (src/Snapshot.cxx:83-158).
 const Snapshot& operator>>(const Snapshot& snap, Wavenet& wavenet) {
-    std::string tmp;
-    std::ifstream stream(snap.file());
-
-    stream >> wavenet.m_lambda;
-    stream >> wavenet.m_alpha;
-    stream >> wavenet.m_inertia;
-    stream >> wavenet.m_inertiaTimeScale;
-
-    // filter and momentum: numbers up to the first token that holds a '#'      (src/Snapshot.cxx:97-113)
-    double value;
-    std::vector<double> numbers;
-    while (stream >> tmp && tmp.find("#") == std::string::npos) {
-        if (toNumber(tmp, &value)) numbers.push_back(value);
+    std::vector<std::string> tokens;
+    {
+        std::ifstream stream(snap.file());
+        std::string token;
+        while (stream >> token) tokens.push_back(token);
     }
-    wavenet.m_filter = toCol(numbers);
-    numbers.clear();
-    while (stream >> tmp && tmp.find("#") == std::string::npos) {
-        if (toNumber(tmp, &value)) numbers.push_back(value);
-    }
-    wavenet.m_momentum = toCol(numbers);
+    std::size_t at = 0;
+    const auto more = [&]() { return at < tokens.size(); };
+    const auto scalar = [&](double fallback) {
+        double v = fallback;
+        if (more() && toNumber(tokens[at], &v)) at++;
+        return v;
+    };
+    // numbers up to and including the first token with a '#' (other words in between are passed over)
+    const auto closedVector = [&]() {
+        std::vector<double> numbers;
+        double v;
+        while (more()) {
+            const std::string& token = tokens[at++];
+            if (token.find('#') != std::string::npos) break;
+            if (toNumber(token, &v)) numbers.push_back(v);
+        }
+        return toCol(numbers);
+    };
+    // the run of numbers at the cursor; `closer` receives the token behind it (empty at the end of the file)
+    const auto run = [&](std::string* closer) {
+        std::vector<double> numbers;
+        double v;
+        while (more() && toNumber(tokens[at], &v)) { numbers.push_back(v); at++; }
+        *closer = more() ? tokens[at++] : std::string();
+        return numbers;
+    };
 
-    stream >> wavenet.m_batchSize;
+    wavenet.m_lambda = scalar(wavenet.m_lambda);
+    wavenet.m_alpha = scalar(wavenet.m_alpha);
+    wavenet.m_inertia = scalar(wavenet.m_inertia);
+    wavenet.m_inertiaTimeScale = scalar(wavenet.m_inertiaTimeScale);
+    wavenet.m_filter = closedVector();
+    wavenet.m_momentum = closedVector();
+    wavenet.m_batchSize = (unsigned)scalar((double)wavenet.m_batchSize);
 
-    // batch queue: vectors of numbers, each ended by a token that is no number   (src/Snapshot.cxx:117-129)
-    stream >> tmp;
+    enum Section { QUEUE, FILTERS, COSTS };
+    const char* const nextName[] = {"FILTERLOG", "COSTLOG"};
+    Section section = QUEUE;
+    std::string closer = more() ? tokens[at++] : std::string();           // the queue's own name
+    if (closer.find(nextName[QUEUE]) != std::string::npos) section = FILTERS;    // (a file without a queue section)
     wavenet.m_batchQueue.clear();
-    while (tmp.find("FILTERLOG") == std::string::npos) {
-        numbers.clear();
-        while (stream >> tmp) {
-            if (!toNumber(tmp, &value)) break;
-            numbers.push_back(value);
-        }
-        if (numbers.empty()) break;
-        wavenet.m_batchQueue.push_back(toCol(numbers));
-    }
-
-    // filter log                                                                  (src/Snapshot.cxx:131-142)
     wavenet.m_filterLog.clear();
-    while (tmp.find("COSTLOG") == std::string::npos) {
-        numbers.clear();
-        while (stream >> tmp) {
-            if (!toNumber(tmp, &value)) break;
-            numbers.push_back(value);
-        }
-        if (numbers.empty()) break;
-        wavenet.m_filterLog.push_back(toCol(numbers));
+    while (section != COSTS) {
+        const std::vector<double> numbers = run(&closer);
+        if (!numbers.empty()) (section == QUEUE ? wavenet.m_batchQueue : wavenet.m_filterLog).push_back(toCol(numbers));
+        if (numbers.empty() || closer.empty() || closer.find(nextName[section]) != std::string::npos) section = (Section)(section + 1);
     }
-
-    // cost log: every remaining number                                            (src/Snapshot.cxx:144-152)
     wavenet.m_costLog.clear();
-    while (!stream.fail()) {
-        while (stream >> tmp) {
-            if (!toNumber(tmp, &value)) break;
-            wavenet.m_costLog.push_back(value);
-        }
+    double v;
+    for (; more(); at++) {
+        if (toNumber(tokens[at], &v)) wavenet.m_costLog.push_back(v);
     }
     return snap;
 }

@@ -31,7 +31,16 @@ def allreduce_sums(sums, world_size, group=None):
 
 
 class DataParallelTrainer:
-    """Drives wn_train_batch -> all-reduce -> wn_apply_update for one rank."""
+    """Drives wn_train_batch -> all-reduce -> wn_apply_update for one rank.
+
+    The all-reduce is ordered on torch's current stream, so the context's kernels have to run on that
+    stream too, or the collective could read the sums before the batch reduction has written them.
+    The trainer therefore REBINDS `ctx` (wn_set_stream) to torch's current stream: once when it is made,
+    and again in step() whenever the current stream differs from the one bound last (a step() under
+    `torch.cuda.stream(s)` moves the context to `s`; wn_set_stream waits for the work on the former
+    stream first).  The binding, like the sums buffer set here, stays with the context after the
+    trainer is gone: a caller that goes on using the context on a stream of its own sets it again.
+    """
 
     def __init__(self, ctx, world_size=1, group=None):
         import torch
@@ -39,16 +48,23 @@ class DataParallelTrainer:
         self.ctx = ctx
         self.world_size = world_size
         self.group = group
-        # the all-reduce is ordered on torch's current stream: the context's kernels must be on it too,
-        # or the collective could read the sums before the batch reduction has written them
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        self._stream = None
+        self._bind_stream()
         self._buf = torch.zeros(WN_MAX_TAPS + 2, dtype=torch.float64, device="cuda")
         ctx.set_sums_buffer(self._buf)
+
+    def _bind_stream(self):
+        import torch
+        stream = torch.cuda.current_stream().cuda_stream
+        if stream != self._stream:
+            self.ctx.set_stream(stream)
+            self._stream = stream
 
     def step(self, X_dev, B_local, R, C, lam, alpha, inertia_eff=0.0, wavelet=True, B_total=None):
         """One batch: B_local examples here, B_total over all ranks (default B_local * world_size)."""
         if B_total is None:
             B_total = B_local * self.world_size
+        self._bind_stream()
         if self.world_size == 1:
             # one submission; up to 4096 samples per example one kernel launch (wn_train_step)
             self.ctx.train_step(X_dev, B_local, R, C, B_total, lam * B_total, alpha, inertia_eff, wavelet)
