@@ -421,3 +421,52 @@ def test_bucket_ranking(oracle, capfd, monkeypatch, n, B):
     finally:
         buckets.close()
         radix.close()
+
+
+@pytest.mark.parametrize("R,C,N,B", [(128, 128, 4, 300), (256, 128, 8, 260), (128, 512, 2, 256), (512, 512, 4, 256)])
+def test_histograms_built_by_the_column_kernel(oracle, R, C, N, B):
+    """With an example per CU or more and both passes on the line kernels, the column kernel leaves the ranking's
+    histograms and largest magnitudes itself (kc_fwd_cols_hist) instead of kr_hist reading the coefficients
+    back.  The histograms are the same numbers, so every sum and per-example value is bit for bit the one of the
+    path with WAVENET_HIP_FUSED_HIST=0; two examples are checked against the oracle.  Examples scaled by 1e-30 and
+    1e30 sit far from the others' magnitudes; in the second batch the taps are scaled by 1e4, which puts the
+    kernel's bound on the largest magnitude so far above the truth that it hands every example to kr_hist; a NaN
+    in one example goes the same way."""
+    import torch
+    from wavenet_amd import generators as G
+    a = filt_for(N, 2)
+    X = G.calorimeter(B, R, C, seed=4)
+    X[1] *= 1e-30
+    X[2] *= 1e30
+    fused = _ctx_with_env("WAVENET_HIP_FUSED_HIST", "1")
+    plain = _ctx_with_env("WAVENET_HIP_FUSED_HIST", "0")
+    try:
+        dX = to_dev(X)
+        out = {}
+        for name, c in (("fused", fused), ("plain", plain)):
+            c.set_filter(a)
+            dG, dS = dev_empty(B * N), dev_empty(B)
+            c.train_batch(dX, B, R, C, dG, dS)
+            out[name] = (c.sums().copy(), dG.cpu().numpy().reshape(B, N), dS.cpu().numpy())
+        for k in range(3):
+            assert np.array_equal(out["fused"][k], out["plain"][k]), k
+        assert out["fused"][0][N + 1] == 0
+        for e in (0, 1, 2):
+            ge, se, _ = oracle.band_train_batch(a, X[e:e + 1])
+            assert relerr(out["fused"][1][e], ge) < 1e-9
+            assert out["fused"][2][e] == pytest.approx(se, rel=1e-11)
+        # the bound too far above the truth, and a non-finite example
+        X[5, 3, 2] = np.nan
+        dX = to_dev(X)
+        for name, c in (("fused", fused), ("plain", plain)):
+            c.set_filter(1e4 * a)
+            dG, dS = dev_empty(B * N), dev_empty(B)
+            c.train_batch(dX, B, R, C, dG, dS)
+            out[name] = (c.sums().copy(), dG.cpu().numpy().reshape(B, N), dS.cpu().numpy())
+        for k in range(3):
+            assert np.array_equal(out["fused"][k], out["plain"][k], equal_nan=True), k
+        assert out["fused"][0][N + 1] > 0
+    finally:
+        torch.cuda.synchronize()
+        fused.close()
+        plain.close()

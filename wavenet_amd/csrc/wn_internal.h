@@ -30,6 +30,8 @@ struct wn_context {
     size_t grid_scratch_count = 0;
     bool bucket_rank = true;  // streamed path: ranks by histogram + per-bucket LDS sort (WAVENET_HIP_RANK=radix: device-wide radix sort)
     bool rank_configured = false;   // the ranking kernels' LDS limits have been raised on this context's device
+    int row_line_taps = 16;   // streamed path: the row passes run on the one-wave-per-line kernels up to this many taps (WAVENET_HIP_ROW_LINE_TAPS)
+    bool fused_hist = true;   // streamed path, 2D on lines: the column kernel builds the ranking's histograms (WAVENET_HIP_FUSED_HIST=0: kr_hist)
     bool rank_packed = true;  // streamed path: 8-byte packed staging keys (WAVENET_HIP_RANK_KEYS=12: magnitudes and indices side by side)
     int rank_sub = 0;         // streamed path: examples per partition + bucket-sort launch pair (WAVENET_HIP_RANK_SUB; 0: the whole chunk)
     int chunk_cap = 0;        // streamed path: examples per chunk at most (WAVENET_HIP_CHUNK; 0: as many as the workspace limit allows)

@@ -31,7 +31,8 @@ namespace wn {
 namespace {
 
 // One-wave-per-line kernels (wn_lines.h, compiled per tap count in wn_lines_np.hip, up to 16 taps).
-enum { LN_FWD_COLS = 0, LN_BWD_COLS = 1, LN_BWD_COLS_RANKS = 2, LN_FWD_ROWS = 3, LN_GRAD_ROWS = 4 };
+enum { LN_FWD_COLS = 0, LN_BWD_COLS = 1, LN_BWD_COLS_RANKS = 2, LN_FWD_ROWS = 3, LN_GRAD_ROWS = 4, LN_FWD_COLS_HIST = 5 };
+constexpr int LN_HIST_T = 1024, LN_HIST_BINS = 36864;   // kc_fwd_cols_hist (wn_lines.h)
 const void* line_kernel(int np, int kind, int M) {
     switch (np) {
         case 2: return wn_kernel_lines_np2(kind, M);
@@ -1034,22 +1035,31 @@ int gini_big(wn_context* ctx, const double* Y, double* D, int B, size_t n, doubl
     return WN_OK;
 }
 
+// Histogram bins of the bucket ranking for examples of n coefficients, and log2 of the bins per octave (NF / RK_OCTAVES).
+void rank_bins(size_t n, int* NF, int* lgBPO) {
+    *NF = (int)std::min<size_t>(rk::RK_NFMAX, std::max<size_t>(1024, n / 2));
+    *lgBPO = 0;
+    while ((rk::RK_OCTAVES << *lgBPO) < *NF) (*lgBPO)++;
+}
+
 // Ranks by histogram and per-bucket LDS sort (wn_rank.h).  Leaves 32-bit ranks at home positions in keysB
 // (example e at (unsigned*)keysB + e * n), {f, g} in fg, the sparsity terms in S_e, and with D the errors.
 // *ok = false: some bucket would overflow (or the example is too long) -- nothing usable was written.
 // kmax: B words, and 16 spare ones of which one serves as the give-up flag; kmax_ready: the producer of Y has raised
 // them already (and its caller zeroed all B + 16 words before that).
+// hist_need (with kmax_ready): the producer has also left the histograms (in idxB, where kr_hist puts them) of all
+// examples but those it marked in hist_need[e].
 int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB, unsigned* idxA,
-                 unsigned* idxB, double* fg, double* S_e, unsigned* kmax, bool kmax_ready, bool* ok, const unsigned** pending = nullptr) {
+                 unsigned* idxB, double* fg, double* S_e, unsigned* kmax, bool kmax_ready, bool* ok, const unsigned** pending = nullptr,
+                 const unsigned* hist_need = nullptr) {
     using namespace rk;
     *ok = false;
     int lgn = 0;
     while (((size_t)1 << lgn) < n) lgn++;
     if (lgn > RK_LGN_MAX || n < 8192) return WN_OK;
     hipStream_t st = ctx->stream;
-    const int NF = (int)std::min<size_t>(RK_NFMAX, std::max<size_t>(1024, n / 2));
-    int lgBPO = 0;
-    while ((RK_OCTAVES << lgBPO) < NF) lgBPO++;   // bins per octave: NF / RK_OCTAVES
+    int NF, lgBPO;
+    rank_bins(n, &NF, &lgBPO);
     const int nbmax = nbmax_for(n);
     unsigned* hist = idxB;                                                           // B * NF words
     unsigned short* btab = reinterpret_cast<unsigned short*>(idxB + (size_t)B * NF);  // B * NF half words
@@ -1075,8 +1085,13 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
         WN_HIP(ctx, hipMemsetAsync(kmax, 0, (size_t)(B + 16) * sizeof(unsigned), st));
         hipLaunchKernelGGL(kr_max, dim3(G, B), dim3(RK_PT), 0, st, Y, n, kmax);
     }
-    if (G > 1) WN_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)B * NF * sizeof(unsigned), st));
-    hipLaunchKernelGGL(kr_hist, dim3(G, B), dim3(RK_PT), (size_t)NF * 4, st, Y, n, kmax, hist, NF, lgBPO);
+    if (kmax_ready && hist_need) {
+        // the few examples the producer could not do: one workgroup each, plain stores
+        hipLaunchKernelGGL(kr_hist, dim3(1, B), dim3(RK_PT), (size_t)NF * 4, st, Y, n, kmax, hist, NF, lgBPO, hist_need);
+    } else {
+        if (G > 1) WN_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)B * NF * sizeof(unsigned), st));
+        hipLaunchKernelGGL(kr_hist, dim3(G, B), dim3(RK_PT), (size_t)NF * 4, st, Y, n, kmax, hist, NF, lgBPO, (const unsigned*)nullptr);
+    }
     hipLaunchKernelGGL(kr_scan, dim3(B), dim3(RK_BT), (size_t)NF * 4, st, hist, kmax, NF, lgBPO, n, btab, meta, flag);
     const int sub = ctx->rank_sub > 0 ? std::min(ctx->rank_sub, B) : B;
     const bool packed = ctx->rank_packed;
@@ -1136,7 +1151,7 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
 int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB,
                unsigned* idxA, unsigned* idxB, unsigned* cnt, double* gpart, double* fg, double* S_e, void* sort_tmp,
                size_t sort_tmp_bytes, int* rank_slice = nullptr, bool counts_ready = false, unsigned* kmax = nullptr,
-               bool kmax_ready = false, const unsigned** pending = nullptr) {
+               bool kmax_ready = false, const unsigned** pending = nullptr, const unsigned* hist_need = nullptr) {
     // rank_slice (with D null): receives the number of examples per slice when the ranks were left in keysB
     // (slice s at keysB + s * slice * n, as 32-bit ranks at home positions) for a consumer that computes
     // the errors itself, 0 when this path did not apply and only the sums were computed.
@@ -1146,7 +1161,7 @@ int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, dou
     while (((size_t)1 << lgn) < n) lgn++;
     if (ctx->bucket_rank && !ctx->exact_sort && kmax) {
         bool ok = false;
-        const int rc = gini_buckets(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, fg, S_e, kmax, kmax_ready, &ok, pending);
+        const int rc = gini_buckets(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, fg, S_e, kmax, kmax_ready, &ok, pending, hist_need);
         if (rc) return rc;
         if (ok) {
             if (rank_slice) *rank_slice = B;   // one slice: example e's ranks at (unsigned*)keysB + e * n
@@ -1255,7 +1270,7 @@ int make_plan(wn_context* ctx, int B, size_t n, int NP, int N, Plan* pl) {
         pl->idxA = c.take<unsigned>(Bc * n);
         pl->idxB = c.take<unsigned>(Bc * n);
         pl->cnt = c.take<unsigned>(Bc * (n / CP_BLOCK + 1) + 3 * Bc + 64);
-        pl->kmax = c.take<unsigned>(Bc + 16);
+        pl->kmax = c.take<unsigned>(3 * Bc + 16);   // kmax[Bc], 16 spare words, then kc_fwd_cols_hist's bound inputs [Bc] and marks [Bc]
         pl->gpart = c.take<double>(Bc * GXMAX * 2);
         pl->fg = c.take<double>(Bc * 2);
         pl->partial = c.take<double>(Bc * (size_t)pgx * 2 * NP);
@@ -1294,19 +1309,26 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         double* YD = Yout ? Yout + (size_t)e0 * n : pl.YD;
         // Lines of 128 .. 1024 samples go through the one-wave-per-line kernels (wn_lines.h): rows in tiles of
         // 16 (8) adjacent rows through LDS, columns directly.  No pyramid is written unless the caller asked
-        // for it -- the backward kernels rebuild it in registers.  Rows up to 8 taps, columns up to 16 (at 16 for lines
-        // of 256 and 512 only: measured neutral at 1024, slower at 128): beyond,
-        // the cross-lane halos and the replicated small levels of the register cascade cost more than the extra
-        // passes of the level kernels (measured at 512x512, ms per 1024 images, line kernels against level
-        // kernels: 8 taps 21.6 / 28.3; 16 taps, columns only 31.7, rows only 42.6, neither 36.1; 32 taps, 512
-        // images: columns only 34.1, rows only 48.9, neither 29.7).
+        // for it -- the backward kernels rebuild it in registers.  Up to 16 taps (at 16 for lines of 256 and 512
+        // only: measured neutral at 1024, slower at 128): beyond, the cross-lane halos and the replicated small
+        // levels of the register cascade cost more than the extra passes of the level kernels (measured at
+        // 512x512, ms per 2048 images, line kernels against level kernels: 8 taps 21.6 / 28.3 per 1024; 16 taps,
+        // compiled for one wave per SIMD so that nothing spills: rows and columns 31.7, columns only 38.8;
+        // 32 taps, 512 images: columns only 34.1, rows only 48.9, neither 29.7).
         const int R = 1 << lgR, C = 1 << lgC;
         const int Mrow = C / 64, Mcol = R / 64;     // samples per lane
-        const bool rowLines = (NP <= 8 && lgC >= 7 && lgC <= 10 && R >= line_tile_rows(Mrow) && ctx->wave64 && !ProwOut);
+        const bool rowLines = (NP <= ctx->row_line_taps && (NP <= 8 || lgC == 8 || lgC == 9) && lgC >= 7 && lgC <= 10 && R >= line_tile_rows(Mrow) && ctx->wave64 && !ProwOut);
         const bool colLines = ((NP <= 8 || (NP == 16 && (lgR == 8 || lgR == 9))) && lgR >= 7 && lgR <= 10 && lgC > 0 && ctx->wave64);
         const bool buckets = try_buckets && ctx->bucket_rank && !ctx->exact_sort && (lgR + lgC) <= rk::RK_LGN_MAX;
         const double* Yc = YD;
         double* pcolArg = PcolOut ? Pcol : nullptr;
+        // the column kernel also builds the ranking's histograms when both passes run on lines and there is an example per CU
+        int NF = 0, lgBPO = 0;
+        rank_bins(n, &NF, &lgBPO);
+        const bool fusedHist = rowLines && colLines && buckets && !forward_only && !pcolArg && ctx->fused_hist && n >= 8192 &&
+                               Bc >= ctx->numCU && NF <= LN_HIST_BINS;
+        unsigned* kmaxRows = fusedHist ? pl.kmax + Bc + 16 : nullptr;
+        unsigned* histNeed = fusedHist ? pl.kmax + 2 * (size_t)Bc + 16 : nullptr;
         size_t xs = n;
         int ncols = C, nrows = R;
         const FilterDev* dfilt = ctx->dfilt;
@@ -1320,12 +1342,22 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
             // LDS beyond the default limit
             WN_HIP(ctx, hipFuncSetAttribute(fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_tile_bytes(Mrow)));
             WN_HIP(ctx, hipFuncSetAttribute(grd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_tile_bytes(Mrow)));
-            void* args[] = {(void*)&Xc, (void*)&Y1, (void*)&xs, (void*)&nrows, (void*)&dfilt};
+            if (fusedHist) WN_HIP(ctx, hipMemsetAsync(pl.kmax, 0, (size_t)(3 * Bc + 16) * sizeof(unsigned), st));   // the ranking's flag among them
+            void* args[] = {(void*)&Xc, (void*)&Y1, (void*)&xs, (void*)&nrows, (void*)&dfilt, (void*)&kmaxRows};
             WN_HIP(ctx, hipLaunchKernel(fwd, dim3(std::min(R / line_tile_rows(Mrow), LN_GX), Bc), dim3(256), args, line_tile_bytes(Mrow), st));
         } else if ((rc = fwd_pass_big<NP>(ctx, Xc, Prow, Y1, Bc, n, rg))) {
             return rc;
         }
-        if (colLines) {
+        if (fusedHist) {
+            const double* y1c = Y1;
+            const void* fn = line_kernel(NP, LN_FWD_COLS_HIST, Mcol);
+            unsigned* hist = pl.idxB;      // where gini_buckets expects them
+            unsigned* kmaxOut = pl.kmax;
+            WN_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LN_HIST_BINS * 4));
+            void* args[] = {(void*)&y1c, (void*)&YD, (void*)&xs, (void*)&ncols, (void*)&dfilt, (void*)&kmaxRows, (void*)&kmaxOut,
+                            (void*)&histNeed, (void*)&hist, (void*)&NF, (void*)&lgBPO};
+            WN_HIP(ctx, hipLaunchKernel(fn, dim3(Bc), dim3(LN_HIST_T), args, (size_t)LN_HIST_BINS * 4, st));
+        } else if (colLines) {
             const double* y1c = Y1;
             // the Gini phase's first step rides along: non-zero counts per CP_BLOCK coefficients
             // (bucket ranking: the largest exponent word per example; radix ranking: the non-zero counts)
@@ -1345,7 +1377,7 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         // the ranks; otherwise (or when the short-key ranking did not apply) they replace the coefficients in YD
         int rank_slice = 0;
         if (colLines && (rc = gini_large(ctx, YD, nullptr, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp,
-                                         pl.sort_tmp_bytes, &rank_slice, !buckets, buckets ? pl.kmax : nullptr, buckets, pending)))
+                                         pl.sort_tmp_bytes, &rank_slice, !buckets, buckets ? pl.kmax : nullptr, buckets, pending, histNeed)))
             return rc;
         if (!rank_slice &&
             (rc = gini_large(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes,

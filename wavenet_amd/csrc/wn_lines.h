@@ -154,7 +154,12 @@ struct LineGini {
     }
 };
 
-#define LN_BOUNDS(T) __launch_bounds__(T, (NP > 16 ? 1 : 2))
+// From 16 taps on the kernels are compiled for one wave per SIMD (512 registers): at two, the backward kernels
+// of 16 taps keep 300 to 750 bytes per lane in scratch memory and run a quarter to a half slower.
+#ifndef LN_ONE_WAVE_FROM
+#define LN_ONE_WAVE_FROM 16
+#endif
+#define LN_BOUNDS(T) __launch_bounds__(T, (NP >= LN_ONE_WAVE_FROM ? 1 : 2))
 
 // The thread index as a value the compiler cannot see through.  Taken at the top of every pass of a kernel's loop
 // over lines or tiles: the addresses derived from it are then computed where they are used instead of being
@@ -206,6 +211,96 @@ __global__ LN_BOUNDS(256) void kc_fwd_cols(const double* __restrict__ in, double
         for (int o = 32; o > 0; o >>= 1) kmine = max(kmine, (unsigned)__shfl_xor((int)kmine, o, 64));
         if (lane0 == 0 && kmine) atomicMax(&kmax[blockIdx.y], kmine);
     }
+}
+
+// kc_fwd_cols with the first step of the bucket ranking fused in: ONE workgroup of 16 waves per example writes the
+// coefficients and, from the registers they are still in, the example's histogram over the ranking's NF logarithmic
+// bins (wn_rank.h: fine_bin, counted down from the example's largest magnitude) and that largest magnitude's
+// exponent word -- what kr_max and kr_hist would otherwise read the coefficients back for.
+// The largest magnitude is only known at the end, so the workgroup counts over LN_HIST_BINS bins in LDS counted
+// down from a bound that is known beforehand: the largest exponent word of the input (kmax_in, left by the kernel
+// that wrote the input) raised by LEVELS * log2(max(1, sum |a_j|, sum |b_j|)) octaves and one more.  Both
+// binnings cut the same absolute grid (exponent word >> shift), so the histogram below the true maximum is the
+// LDS one moved by (bound - maximum) bins, exactly.  When the bound lies more than LN_HIST_BINS - NF bins above
+// the maximum (or anything exceeds it: non-finite values), need[example] is set instead and kr_hist does that
+// example.  grid (examples), LN_HIST_T threads, LN_HIST_BINS * 4 bytes of dynamic LDS.
+constexpr int LN_HIST_T = 1024;
+constexpr int LN_HIST_BINS = 36864;
+template <int NP, int M>
+__global__ __launch_bounds__(LN_HIST_T) void kc_fwd_cols_hist(const double* __restrict__ in, double* __restrict__ Y, size_t xs, int ncols,
+                                                              const FilterDev* filt, const unsigned* __restrict__ kmax_in,
+                                                              unsigned* kmax, unsigned* need, unsigned* hist, int NF, int lgBPO) {
+    constexpr int LEVELS = 6 + (M == 2 ? 1 : M == 4 ? 2 : M == 8 ? 3 : 4);
+    extern __shared__ unsigned ln_hist[];
+    __shared__ unsigned wred[LN_HIST_T / 64];
+    __shared__ unsigned tail_sum, bad_any;
+    const int tid = threadIdx.x, lane0 = tid & 63, wave = tid >> 6, e = blockIdx.x;
+    for (int j = tid; j < LN_HIST_BINS; j += LN_HIST_T) ln_hist[j] = 0;
+    if (tid == 0) { tail_sum = 0; bad_any = 0; }
+    double a[NP], b[NP];
+    ln_load_taps<NP>(filt, a, b);
+    double sa = 0, sb = 0;
+#pragma unroll
+    for (int j = 0; j < NP; j++) { sa += fabs(a[j]); sb += fabs(b[j]); }
+    const double gain = fmax(1.0, fmax(sa, sb));
+    const double octs = ceil((double)LEVELS * log2(gain) + 1e-6) + 1.0;
+    const int shift = 20 - lgBPO;
+    unsigned badv = 0;
+    unsigned kprov = 0x7FEFFFFFu;
+    if (octs < 1024.0) {
+        const unsigned long long kp = (unsigned long long)kmax_in[e] + ((unsigned long long)octs << 20);
+        if (kp < 0x7FF00000ull) kprov = (unsigned)kp;
+    }
+    const unsigned Lprov = kprov >> shift;
+    __syncthreads();
+    unsigned kmine = 0;
+    const size_t off = (size_t)e * xs;
+    for (int c = wave; c < ncols; c += LN_HIST_T / 64) {
+        const int lane = ln_opaque(lane0);
+        const size_t lo = off + (size_t)c * (64 * M);
+        LinePyramid<M> p;
+        LineLane<M> y;
+        double small_lo;
+        ln_load_samples<M>(in + lo, p.x, lane);
+        ln_forward<NP, M>(p, a, b, lane, y, small_lo);
+        ln_store<M>(Y + lo, y.v, y.v[0], lane);
+#pragma unroll
+        for (int k = 0; k < M; k++) {
+            const unsigned key = (unsigned)__double2hiint(y.v[k]) & 0x7FFFFFFFu;
+            kmine = max(kmine, key);
+            if (y.v[k] != 0.0) {
+                const unsigned L = key >> shift;
+                if (L > Lprov) badv = 1;
+                const unsigned d = (L > Lprov) ? 0u : Lprov - L;
+                atomicAdd(&ln_hist[d < (unsigned)(LN_HIST_BINS - 1) ? d : (unsigned)(LN_HIST_BINS - 1)], 1u);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kmine = max(kmine, (unsigned)__shfl_xor((int)kmine, o, 64));
+    if (lane0 == 0) wred[wave] = kmine;
+    if (badv) bad_any = 1u;
+    __syncthreads();
+    unsigned kmaxW = 0;
+#pragma unroll
+    for (int w = 0; w < LN_HIST_T / 64; w++) kmaxW = max(kmaxW, wred[w]);
+    const unsigned Lmax = kmaxW >> shift;
+    const bool invalid = bad_any != 0 || Lmax > Lprov || Lprov - Lmax > (unsigned)(LN_HIST_BINS - NF);
+    if (tid == 0) {
+        kmax[e] = kmaxW;
+        need[e] = invalid ? 1u : 0u;
+    }
+    if (invalid) return;
+    const unsigned o = Lprov - Lmax;
+    unsigned* out = hist + (size_t)e * NF;
+    unsigned t = 0;      // bin 0 takes all that lies NF - 1 bins or more below the maximum
+    for (unsigned j = o + (unsigned)NF - 1u + (unsigned)tid; j < (unsigned)LN_HIST_BINS; j += LN_HIST_T) t += ln_hist[j];
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) t += (unsigned)__shfl_xor((int)t, s, 64);
+    if (lane0 == 0 && t) atomicAdd(&tail_sum, t);
+    for (int f = 1 + tid; f < NF; f += LN_HIST_T) out[f] = ln_hist[o + (unsigned)(NF - 1 - f)];
+    __syncthreads();
+    if (tid == 0) out[0] = tail_sum;
 }
 
 // Errors on the coefficients of the columns and the columns themselves (in) -> errors on the columns
@@ -292,7 +387,10 @@ template <int M, bool TO_TILE>
 __device__ __forceinline__ void ln_move_tile(double* tile, double* mem, int R, int tid) {
     using T = LineTile<M>;
     const int rp = tid % T::PAIRS;
-#pragma unroll 4
+#ifndef LN_MOVE_UNROLL
+#define LN_MOVE_UNROLL 4
+#endif
+#pragma unroll LN_MOVE_UNROLL
     for (int it = 0; it < T::STEPS; it++) {
         const int c = tid / T::PAIRS + T::COLS_PER_STEP * it;
         double2* g = reinterpret_cast<double2*>(mem + 2 * rp + (size_t)R * c);
@@ -304,6 +402,35 @@ __device__ __forceinline__ void ln_move_tile(double* tile, double* mem, int R, i
         } else {
             *g = make_double2(t[0], t[T::RS]);
         }
+    }
+}
+// The same move towards the tile in two halves: the global reads into registers (all in flight at once), and
+// from the registers into the tile.  A kernel that needs two tiles one after the other through the one LDS
+// buffer issues the reads of both before it waits for either.
+template <int M>
+struct LineTileRegs {
+    double2 v[LineTile<M>::STEPS];
+};
+template <int M>
+__device__ __forceinline__ void ln_tile_fetch(LineTileRegs<M>& r, const double* mem, int R, int tid) {
+    using T = LineTile<M>;
+    const int rp = tid % T::PAIRS;
+#pragma unroll
+    for (int it = 0; it < T::STEPS; it++) {
+        const int c = tid / T::PAIRS + T::COLS_PER_STEP * it;
+        r.v[it] = *reinterpret_cast<const double2*>(mem + 2 * rp + (size_t)R * c);
+    }
+}
+template <int M>
+__device__ __forceinline__ void ln_tile_put(double* tile, const LineTileRegs<M>& r, int tid) {
+    using T = LineTile<M>;
+    const int rp = tid % T::PAIRS;
+#pragma unroll
+    for (int it = 0; it < T::STEPS; it++) {
+        const int c = tid / T::PAIRS + T::COLS_PER_STEP * it;
+        double* t = tile + (2 * rp) * T::RS + T::pad(c);
+        t[0] = r.v[it].x;
+        t[T::RS] = r.v[it].y;
     }
 }
 // one row of the tile <-> samples / lane layout
@@ -332,13 +459,15 @@ __device__ __forceinline__ void ln_row_load(const double* row, LineLane<M>& y, i
 }
 
 // Forward over the rows: grid (tiles per example <= R / ROWS, examples), 256 threads, LineTile<M>::BYTES of LDS.
+// kmax_out (may be null): kmax_out[example] is raised to the largest exponent word among the example's row coefficients.
 template <int NP, int M>
 __global__ LN_BOUNDS(256) void kr_fwd_rows(const double* __restrict__ in, double* __restrict__ Y, size_t xs, int R,
-                                           const FilterDev* filt) {
+                                           const FilterDev* filt, unsigned* kmax_out) {
     using T = LineTile<M>;
     extern __shared__ __attribute__((aligned(16))) double ln_tile[];
     double a[NP], b[NP];
     ln_load_taps<NP>(filt, a, b);
+    unsigned kmine = 0;
     for (int tile = blockIdx.x; tile < R / T::ROWS; tile += gridDim.x) {
         const int tid = ln_opaque((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
         const size_t base = (size_t)blockIdx.y * xs + (size_t)tile * T::ROWS;
@@ -353,9 +482,29 @@ __global__ LN_BOUNDS(256) void kr_fwd_rows(const double* __restrict__ in, double
             ln_row_samples<M>(row, p.x, lane);
             ln_forward<NP, M>(p, a, b, lane, y, unused_lo);
             ln_row_store<M>(row, y, lane);      // in place: the row is in this wave's registers
+            if (kmax_out) {
+#pragma unroll
+                for (int k = 0; k < M; k++) kmine = max(kmine, (unsigned)__double2hiint(y.v[k]) & 0x7FFFFFFFu);
+            }
         }
         __syncthreads();
         ln_move_tile<M, false>(ln_tile, Y + base, R, tid);
+    }
+    if (kmax_out) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kmine = max(kmine, (unsigned)__shfl_xor((int)kmine, o, 64));
+#ifndef LN_KMAX_PER_WAVE
+        __syncthreads();                    // the tile is free: one atomic per workgroup
+        unsigned* red = reinterpret_cast<unsigned*>(ln_tile);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = kmine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            kmine = max(max(red[0], red[1]), max(red[2], red[3]));
+            if (kmine) atomicMax(&kmax_out[blockIdx.y], kmine);
+        }
+#else
+        if ((threadIdx.x & 63) == 0 && kmine) atomicMax(&kmax_out[blockIdx.y], kmine);
+#endif
     }
 }
 
@@ -376,6 +525,21 @@ __global__ LN_BOUNDS(256) void kr_grad_rows(const double* __restrict__ coef, con
         const int tid = ln_opaque((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
         const size_t base = (size_t)blockIdx.y * xs + (size_t)tile * T::ROWS;
         double xr[PER_WAVE][M];
+#ifdef LN_GRAD_EARLY
+        {
+            LineTileRegs<M> tin, tco;
+            ln_tile_fetch<M>(tin, in + base, R, tid);
+            ln_tile_fetch<M>(tco, coef + base, R, tid);
+            __syncthreads();
+            ln_tile_put<M>(ln_tile, tin, tid);
+            __syncthreads();
+#pragma unroll
+            for (int jj = 0; jj < PER_WAVE; jj++) ln_row_samples<M>(ln_tile + (wave + 4 * jj) * T::RS, xr[jj], lane);
+            __syncthreads();
+            ln_tile_put<M>(ln_tile, tco, tid);
+            __syncthreads();
+        }
+#else
         __syncthreads();
         ln_move_tile<M, true>(ln_tile, const_cast<double*>(in) + base, R, tid);
         __syncthreads();
@@ -384,6 +548,7 @@ __global__ LN_BOUNDS(256) void kr_grad_rows(const double* __restrict__ coef, con
         __syncthreads();
         ln_move_tile<M, true>(ln_tile, const_cast<double*>(coef) + base, R, tid);
         __syncthreads();
+#endif
 #pragma unroll
         for (int jj = 0; jj < PER_WAVE; jj++) {
             LinePyramid<M> p;
