@@ -34,12 +34,13 @@ WORKLOADS = {
     "2d512": (512, 512, 2048, 4, "calorimeter", 8.0),    # streamed path; 16384 images over 8 GPUs
     "2d512n16": (512, 512, 2048, 16, "calorimeter", 5.0),
     "1d1m": (1 << 20, 1, 8, 32, "bumps", 6.0),           # streamed path, 8 signals per GPU
+    "1d1mb64": (1 << 20, 1, 64, 32, "bumps", 6.0),       # the same with 64 signals per GPU: enough work per launch
 }
 HEADLINE = "2d64"
-ALL_ORDER = ["2d64n16", "1d1024", "2d512", "2d512n16", "1d1m", HEADLINE]
+ALL_ORDER = ["2d64n16", "1d1024", "2d512", "2d512n16", "1d1m", "1d1mb64", HEADLINE]
 # Distinct resident batches the timed steps rotate over, so that more than the 256 MiB Infinity Cache lies between two
 # uses of an input (64x64: 3 x 134 MB); a batch of 512x512 images (4.3 GB) is beyond it by itself.
-ROTATE = {"2d64": 3, "2d64n16": 3, "1d1024": 10, "2d512": 1, "2d512n16": 1, "1d1m": 6}
+ROTATE = {"2d64": 3, "2d64n16": 3, "1d1024": 10, "2d512": 1, "2d512n16": 1, "1d1m": 6, "1d1mb64": 1}
 
 # What actually limits the dominant kernel (the graded roofline fraction prices the step in the bytes an
 # unfused pipeline would move; these kernels keep most of those passes on chip).
@@ -48,8 +49,9 @@ LIMITER = {
     "2d64n16": "VALU issue (filter cascade and sort) with one wave per SIMD",
     "1d1024": "VALU issue: the Gini phase (sort and ranks) is most of the kernel's instructions",
     "2d512": "HBM passes of the per-example ranking and of the four line-transform kernels",
-    "2d512n16": "the level-by-level row pass of 16-tap filters (L1 / LDS requests) and the ranking",
+    "2d512n16": "LDS crossbar: the cross-lane gathers of the six replicated small levels of every line, 16 per level and direction",
     "1d1m": "kernel count and tail latency: 8 signals per step give each launch little work",
+    "1d1mb64": "HBM passes of the level-by-level transform (32 taps) and of the ranking",
 }
 
 

@@ -1095,14 +1095,16 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
     hipLaunchKernelGGL(kr_scan, dim3(B), dim3(RK_BT), (size_t)NF * 4, st, hist, kmax, NF, lgBPO, n, btab, meta, flag);
     const int sub = ctx->rank_sub > 0 ? std::min(ctx->rank_sub, B) : B;
     const bool packed = ctx->rank_packed;
-    const int steps = (int)(n / RK_REGION), nbe = nbmax_even(n);    // regions per example
+    const int steps_max = (int)(n >> RK_IB_MIN), nbe = nbmax_even(n);    // regions per example at most: what the snapshots are sized for
     // packed staging: cursor snapshots and (several workgroups per example) kr_count's counts in place of the index array
     unsigned short* snap = reinterpret_cast<unsigned short*>(idxA);
-    unsigned* precnt = idxA + ((size_t)B * steps * nbe + 1) / 2;
+    unsigned* precnt = idxA + ((size_t)B * steps_max * nbe + 1) / 2;
     for (int s0 = 0; s0 < B; s0 += sub) {
         const int Bs = std::min(sub, B - s0);
         int Gs = 1;
-        while ((long long)Gs * Bs < 2LL * ctx->numCU && n / (2 * (size_t)Gs) >= (size_t)std::max(RK_TILE, RK_REGION)) Gs *= 2;   // (whole regions per workgroup)
+        while ((long long)Gs * Bs < 2LL * ctx->numCU && n / (2 * (size_t)Gs) >= (size_t)std::max(RK_TILE, 1 << RK_IB_MIN)) Gs *= 2;   // (whole regions per workgroup)
+        const int ib = rank_ib(lgn, n / (size_t)Gs);
+        const int steps = (int)(n >> ib);
         const double* Ys = Y + (size_t)s0 * n;
         const unsigned short* bts = btab + (size_t)s0 * NF;
         unsigned* ms = meta + (size_t)s0 * meta_words(n);
@@ -1115,12 +1117,12 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
                 hipLaunchKernelGGL(kr_count, dim3(Gs, Bs), dim3(RK_PT), (size_t)NF * 2, st, Ys, n, bts, ms, NF, lgBPO, precnt, flag);
                 pc = precnt;
             }
-            hipLaunchKernelGGL(kr_part8, dim3(Gs, Bs), dim3(RK_PT), (size_t)NF * 2, st, Ys, n, bts, ms, NF, lgBPO, mag, sn, pc, flag);
-            hipLaunchKernelGGL((kr_bucket<RK_LGNSB, true>), dim3(bgrid), dim3(RK_KT), 0, st, mag, (const unsigned*)nullptr, sn, Ys, n, lgn, ms, rks, Bs, flag, NF, lgBPO);
+            hipLaunchKernelGGL(kr_part8, dim3(Gs, Bs), dim3(RK_PT), (size_t)NF * 2, st, Ys, n, bts, ms, NF, lgBPO, mag, sn, pc, flag, ib);
+            hipLaunchKernelGGL((kr_bucket<RK_LGNSB, true>), dim3(bgrid), dim3(RK_KT), 0, st, mag, (const unsigned*)nullptr, sn, Ys, n, lgn, ms, rks, Bs, flag, NF, lgBPO, ib);
         } else {
             if (Gs == 1) hipLaunchKernelGGL(kr_part<true>, dim3(1, Bs), dim3(RK_PT), (size_t)NF * 2, st, Ys, n, bts, ms, NF, lgBPO, mag, idxA, flag);
             else hipLaunchKernelGGL(kr_part<false>, dim3(Gs, Bs), dim3(RK_PT), (size_t)NF * 2, st, Ys, n, bts, ms, NF, lgBPO, mag, idxA, flag);
-            hipLaunchKernelGGL((kr_bucket<RK_LGNSB, false>), dim3(bgrid), dim3(RK_KT), 0, st, mag, idxA, (const unsigned short*)nullptr, Ys, n, lgn, ms, rks, Bs, flag, NF, lgBPO);
+            hipLaunchKernelGGL((kr_bucket<RK_LGNSB, false>), dim3(bgrid), dim3(RK_KT), 0, st, mag, idxA, (const unsigned short*)nullptr, Ys, n, lgn, ms, rks, Bs, flag, NF, lgBPO, 0);
         }
     }
     hipLaunchKernelGGL(kr_finish, dim3(B), dim3(64), 0, st, meta, n, B, fg, S_e);

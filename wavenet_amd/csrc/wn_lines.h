@@ -156,6 +156,29 @@ struct LineGini {
 
 // From 16 taps on the kernels are compiled for one wave per SIMD (512 registers): at two, the backward kernels
 // of 16 taps keep 300 to 750 bytes per lane in scratch memory and run a quarter to a half slower.
+// Errors on the coefficients of the levels with CC, 2 CC, ... values per lane from their ranks: a lane's CC ranks of
+// a level are consecutive words (8- and 16-byte loads).
+template <int M, int CC>
+__device__ __forceinline__ void ln_delta_levels(LineLane<M>& dy, const LineGini& gini, const unsigned* rc, int lane) {
+    if constexpr (CC < M) {
+        if constexpr (CC == 2) {
+            const uint2 r = *reinterpret_cast<const uint2*>(rc + 128 + 2 * lane);
+            dy.v[2] = gini.delta(dy.v[2], r.x);
+            dy.v[3] = gini.delta(dy.v[3], r.y);
+        } else {
+#pragma unroll
+            for (int m = 0; m < CC; m += 4) {
+                const uint4 r = *reinterpret_cast<const uint4*>(rc + 64 * CC + CC * lane + m);
+                dy.v[CC + m] = gini.delta(dy.v[CC + m], r.x);
+                dy.v[CC + m + 1] = gini.delta(dy.v[CC + m + 1], r.y);
+                dy.v[CC + m + 2] = gini.delta(dy.v[CC + m + 2], r.z);
+                dy.v[CC + m + 3] = gini.delta(dy.v[CC + m + 3], r.w);
+            }
+        }
+        ln_delta_levels<M, 2 * CC>(dy, gini, rc, lane);
+    }
+}
+
 #ifndef LN_ONE_WAVE_FROM
 #define LN_ONE_WAVE_FROM 16
 #endif
@@ -307,7 +330,8 @@ __global__ __launch_bounds__(LN_HIST_T) void kc_fwd_cols_hist(const double* __re
 // (out, may be null: last pass) and the window sums of the filter gradient, added to
 // partial[(example * LN_GX + workgroup) * 2 NP + u] as the level kernels do.  The errors on the
 // coefficients are read from coef, or with FROM_RANKS computed on the way in from the coefficients
-// (coef), their ranks and the example's sums fg = {f, g}: the array of errors is then never written.
+// (recomputed from the columns; coef is not read), their ranks and the example's sums fg = {f, g}: the array of
+// errors is then never written.
 // ranks: per slice of `slice` examples an array of slice * n ranks at ranks + slice_first_example * n
 // DOUBLES (the streamed path's layout).
 template <int NP, int M, bool FROM_RANKS>
@@ -336,20 +360,18 @@ __global__ LN_BOUNDS(256) void kc_bwd_cols(const double* __restrict__ coef, cons
         const int lane = ln_opaque(lane0);
         const size_t lo = off + (size_t)c * (64 * M);
         LinePyramid<M> p;
-        LineLane<M> unused_y, dy;
+        LineLane<M> dy;
         double unused_lo;
         ln_load_samples<M>(in + lo, p.x, lane);
-        ln_forward<NP, M>(p, a, b, lane, unused_y, unused_lo);
-        ln_load<M>(coef + lo, dy, lane);          // errors on the coefficients, or the coefficients themselves
+        // FROM_RANKS: the coefficients come out of the cascade that rebuilds the pyramid -- the very instructions that
+        // produced the stored ones, so the same bits -- and are not read from memory
+        ln_forward<NP, M>(p, a, b, lane, dy, unused_lo);
+        if constexpr (!FROM_RANKS) ln_load<M>(coef + lo, dy, lane);          // errors on the coefficients
         if constexpr (FROM_RANKS) {
             const unsigned* rc = rk + (size_t)c * (64 * M);
             dy.v[0] = gini.delta(dy.v[0], rc[lane]);
             dy.v[1] = gini.delta(dy.v[1], rc[64 + lane]);
-#pragma unroll
-            for (int cc = 2; cc < M; cc *= 2) {
-#pragma unroll
-                for (int m = 0; m < cc; m++) dy.v[cc + m] = gini.delta(dy.v[cc + m], rc[64 * cc + cc * lane + m]);
-            }
+            ln_delta_levels<M, 2>(dy, gini, rc, lane);
         }
         double dtop[M];
         if (out) {

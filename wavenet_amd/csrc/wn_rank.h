@@ -43,12 +43,17 @@ constexpr int RK_KE = 8;         // magnitudes (and sub-bins) per thread of kr_b
 constexpr int RK_LGNSB = 12;     // log2 of the sub-bins of a bucket
 constexpr int RK_NBMAX = 1024;   // buckets per example at most: examples of up to 2^21 coefficients
 constexpr int RK_LGN_MAX = 21;
-#ifndef RK_IB_BITS
-#define RK_IB_BITS 13
-#endif
-constexpr int RK_IB = RK_IB_BITS;                           // home index bits inside a packed staging key: the position within a region of the example
-constexpr int RK_REGION = 1 << RK_IB;                       // consecutive home positions that share the rest of their index
-constexpr int RK_STEPS_MAX = (1 << RK_LGN_MAX) >> RK_IB;    // regions per example at most
+// Packed staging keys carry the home index modulo a region of 2^ib positions (the rest of the index comes from cursor
+// snapshots per region).  ib is chosen per launch: regions of at least 2^RK_IB_MIN positions (whole steps of kr_part8),
+// about 32 of them per example -- kr_bucket follows the regions' boundaries slot by slot, so a bucket that is cut into
+// many regions pays for each boundary -- and whole regions per workgroup of kr_part8.
+constexpr int RK_IB_MIN = 13;
+constexpr int RK_STEPS_MAX = (1 << RK_LGN_MAX) >> RK_IB_MIN;    // regions per example at most
+__host__ __device__ inline int rank_ib(int lgn, size_t per_workgroup) {
+    int ib = lgn - 5 > RK_IB_MIN ? lgn - 5 : RK_IB_MIN;
+    while (ib > RK_IB_MIN && ((size_t)1 << ib) > per_workgroup) ib--;
+    return ib;
+}
 
 // Workgroup barrier for hand-overs through LDS only: waits for this wave's LDS operations, not for its global
 // loads and stores (__syncthreads() also drains those, which would put the memory latency of every prefetch and
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(RK_PT) void kr_part(const double* __restrict__ Y, s
 // the example's coefficients step by step (RK_TILE consecutive home positions per step) and appends to every bucket
 // what the step holds for it, so the keys of step s occupy the positions [snap[s][b], snap[s + 1][b]) of bucket b.
 // kr_part8 leaves those cursor snapshots (16-bit offsets from the bucket's start: a bucket holds at most RK_CAP keys)
-// and kr_bucket recovers home index = (step << RK_IB) | low bits by a search over its bucket's column of them.  A bucket
+// and kr_bucket recovers home index = (step << ib) | low bits by a search over its bucket's column of them.  A bucket
 // wider than 2^53 bit patterns (the lowest one, which reaches down to zero; sparse tails) keeps whatever fits of its
 // magnitudes; kr_bucket reads such a bucket's exact magnitudes back from the coefficients at the home positions.
 // With several workgroups per example each one's cursors start where kr_count says the workgroups before it end, so
@@ -398,8 +403,8 @@ __global__ __launch_bounds__(RK_PT) void kr_count(const double* __restrict__ Y, 
 // grid (G, B), RK_PT threads; dynamic LDS: btab, NF * 2 bytes.  precnt: kr_count's counts (G > 1), else null.
 __global__ __launch_bounds__(RK_PT) void kr_part8(const double* __restrict__ Y, size_t n, const unsigned short* __restrict__ btab,
                                                   const unsigned* __restrict__ meta_all, int NF, int lgBPO, unsigned long long* keys,
-                                                  unsigned short* snap, const unsigned* __restrict__ precnt, const unsigned* flag) {
-    static_assert(RK_TILE == 4 * RK_PT && RK_NBMAX == 2 * RK_PT && RK_REGION % RK_TILE == 0, "four coefficients and two buckets per thread; whole steps per region");
+                                                  unsigned short* snap, const unsigned* __restrict__ precnt, const unsigned* flag, int ib) {
+    static_assert(RK_TILE == 4 * RK_PT && RK_NBMAX == 2 * RK_PT && (1 << RK_IB_MIN) % RK_TILE == 0, "four coefficients and two buckets per thread; whole steps per region");
     extern __shared__ unsigned short rk_bt[];
     __shared__ unsigned cnt[RK_NBMAX], gb[RK_NBMAX], bst[RK_NBMAX], bs0[RK_NBMAX], lo32[RK_NBMAX];
     __shared__ unsigned short lst[RK_NBMAX];     // 79 KB with the rest: two workgroups per CU
@@ -433,7 +438,8 @@ __global__ __launch_bounds__(RK_PT) void kr_part8(const double* __restrict__ Y, 
     const size_t per = n / gridDim.x, first = (size_t)blockIdx.x * per, last = first + per;
     const double* src = Y + (size_t)e * n;
     unsigned long long* ko = keys + (size_t)e * n;
-    unsigned* sn = reinterpret_cast<unsigned*>(snap + (size_t)e * (n / RK_REGION) * nbe);    // two buckets per word
+    unsigned* sn = reinterpret_cast<unsigned*>(snap + (size_t)e * (n >> ib) * nbe);    // two buckets per word
+    const unsigned region_mask = (1u << ib) - 1u;
     double2 nx[2];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
@@ -473,8 +479,8 @@ __global__ __launch_bounds__(RK_PT) void kr_part8(const double* __restrict__ Y, 
             lst[2 * tid] = (unsigned short)run;
             lst[2 * tid + 1] = (unsigned short)(run + c0);
             const unsigned p0 = bst[2 * tid], p1 = bst[2 * tid + 1];
-            if (2 * tid < nbe && (i0 & (size_t)(RK_REGION - 1)) == 0)      // the first step of a region
-                sn[(i0 >> RK_IB) * (size_t)(nbe / 2) + tid] = ((p0 - bs0[2 * tid]) & 0xFFFFu) | ((p1 - bs0[2 * tid + 1]) << 16);
+            if (2 * tid < nbe && ((unsigned)i0 & region_mask) == 0)      // the first step of a region
+                sn[(i0 >> ib) * (size_t)(nbe / 2) + tid] = ((p0 - bs0[2 * tid]) & 0xFFFFu) | ((p1 - bs0[2 * tid + 1]) << 16);
             gb[2 * tid] = p0;
             gb[2 * tid + 1] = p1;
             bst[2 * tid] = p0 + c0;
@@ -486,9 +492,9 @@ __global__ __launch_bounds__(RK_PT) void kr_part8(const double* __restrict__ Y, 
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (bits[k]) {
-                const unsigned within = ((unsigned)i0 & (unsigned)(RK_REGION - 1)) + 2u * (unsigned)((k >> 1) * RK_PT + tid) + (unsigned)(k & 1);    // home index modulo RK_REGION
+                const unsigned within = ((unsigned)i0 & region_mask) + 2u * (unsigned)((k >> 1) * RK_PT + tid) + (unsigned)(k & 1);    // home index modulo the region
                 const unsigned lp = lst[bk[k]] + o[k];
-                keyL[lp] = ((bits[k] - ((unsigned long long)lo32[bk[k]] << 32)) << RK_IB) | within;
+                keyL[lp] = ((bits[k] - ((unsigned long long)lo32[bk[k]] << 32)) << ib) | within;
                 dstL[lp] = gb[bk[k]] + o[k];
             }
         }
@@ -543,7 +549,7 @@ struct BucketHomes {
     const unsigned* ii;
     const unsigned long long* mi;
     const unsigned short* col;
-    int steps;
+    int steps, ib;
     __device__ __forceinline__ unsigned step_of(unsigned j) const {
         int lo = 0, hi = steps;                      // col[lo] <= j < col[hi] (col[steps] = size of the bucket)
         while (hi - lo > 1) {
@@ -554,7 +560,7 @@ struct BucketHomes {
     }
     __device__ __forceinline__ unsigned operator()(unsigned j) const {
         if constexpr (!PACKED8) return ii[j];
-        else return (step_of(j) << RK_IB) | ((unsigned)mi[j] & ((1u << RK_IB) - 1u));
+        else return (step_of(j) << ib) | ((unsigned)mi[j] & ((1u << ib) - 1u));
     }
 };
 
@@ -644,7 +650,7 @@ __device__ __forceinline__ void bucket_ranks(BucketLds<LGNSB>& L, unsigned long 
 template <int LGNSB, bool PACKED8>
 __global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned long long* __restrict__ mag, const unsigned* __restrict__ idx,
                                                                  const unsigned short* __restrict__ snap, const double* __restrict__ Y, size_t n, int lgn,
-                                                                 unsigned* meta_all, unsigned* rank, int B, const unsigned* flag, int NF, int lgBPO) {
+                                                                 unsigned* meta_all, unsigned* rank, int B, const unsigned* flag, int NF, int lgBPO, int ib) {
     constexpr int NSB = 1 << LGNSB;
     constexpr int SPT = NSB / RK_KT;            // sub-bins per thread in the prefix sum
     static_assert(SPT % 4 == 0 && RK_CAP == RK_KE * RK_KT, "whole 16-byte pieces of counters per thread; RK_KE magnitudes per thread");
@@ -681,7 +687,7 @@ __global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned l
     const unsigned f0 = meta_binfirst(meta, nbmax)[b], fnext = meta_binfirst(meta, nbmax)[b + 1];
     unsigned long long lo, hi;
     bin_range(f0, (fnext > f0 ? fnext : (unsigned)NF) - 1u, meta[2], meta[3], lgBPO, NF, &lo, &hi);
-    const int steps = (int)(n >> RK_IB);
+    const int steps = PACKED8 ? (int)(n >> ib) : 0;
     if constexpr (PACKED8) {
         // the bucket's column of cursor snapshots; a slot's step is the last one whose snapshot does not exceed it
         const int nbe = nbmax_even(n);
@@ -689,11 +695,11 @@ __global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned l
         for (int r = tid; r < steps; r += RK_KT) L.col[r] = sc[(size_t)r * nbe];
         if (tid == 0) L.col[steps] = (unsigned short)count;
         lds_barrier();
-        const bool wide = ((hi - lo) >> (64 - RK_IB)) != 0;      // kr_part8 could not keep this bucket's magnitudes whole
+        const bool wide = ((hi - lo) >> (64 - ib)) != 0;      // kr_part8 could not keep this bucket's magnitudes whole
         // A wave's slots are 512 consecutive ones, 64 per k, and the regions' boundaries are the same for every lane: the
         // region of a block's first slot and the boundaries inside the block are followed in scalar registers (reads of
         // one LDS address by the whole wave), and a lane only counts the boundaries that do not exceed its slot.
-        const BucketHomes<true> first{nullptr, mi, L.col, steps};
+        const BucketHomes<true> first{nullptr, mi, L.col, steps, ib};
         const unsigned base0 = (unsigned)__builtin_amdgcn_readfirstlane((int)bucket_slot<true>(tid & ~63, 0));
         unsigned rs = (base0 < count) ? first.step_of(base0) : 0u;
         rs = (unsigned)__builtin_amdgcn_readfirstlane((int)rs);
@@ -711,8 +717,8 @@ __global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned l
                 t++;
                 bnd = (unsigned)__builtin_amdgcn_readfirstlane((int)L.col[t]);
             }
-            id[k] = (r << RK_IB) | ((unsigned)key[k] & ((1u << RK_IB) - 1u));
-            key[k] = lo + (key[k] >> RK_IB);
+            id[k] = (r << ib) | ((unsigned)key[k] & ((1u << ib) - 1u));
+            key[k] = lo + (key[k] >> ib);
             if (wide && j < count) key[k] = (unsigned long long)__double_as_longlong(Y[(size_t)e * n + id[k]]) & 0x7FFFFFFFFFFFFFFFull;
         }
     }
@@ -795,7 +801,7 @@ __global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned l
     lds_barrier();
     unsigned* rk = rank + (size_t)e * n;
     const unsigned rank0 = zeros + s0 + 1u;
-    const BucketHomes<PACKED8> home{ii, mi, L.col, steps};
+    const BucketHomes<PACKED8> home{ii, mi, L.col, steps, ib};
     if (!slots) bucket_ranks<LGNSB, false, PACKED8>(L, key, so, count, PB, home, rk, rank0);
     else bucket_ranks<LGNSB, true, PACKED8>(L, key, so, count, PB, home, rk, rank0);
     double f = 0, a = 0;

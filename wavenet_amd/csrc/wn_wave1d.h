@@ -63,6 +63,88 @@ __device__ __forceinline__ double w1d_uniform(double v) {
                             __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
+// Rotation inside the rows of 16 lanes: lane i receives lane (i - N) mod 16 of its row (DPP row_ror:N).
+template <int N>
+__device__ __forceinline__ double w1d_row_ror(double v) {
+    static_assert(N >= 1 && N <= 15, "row_ror takes 1..15");
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// out[t] = v of lane (lane + S0 + t), t < CNT, for a value that is periodic in the lane number with period P (a
+// power of two up to 64).  Periods up to 16 repeat inside every row of 16 lanes, so one row rotation reaches any
+// distance; the longer periods are followed one lane at a time by rotations of the whole wave, outwards from
+// distance 0.  DPP moves only: nothing goes through the LDS crossbar.  Every lane of the wave must be active.
+template <int S0, int CNT, int P>
+__device__ __forceinline__ void w1d_shifts(double v, double* out) {
+    static_assert(P >= 1 && P <= 64 && (P & (P - 1)) == 0, "period: a power of two up to 64");
+    if constexpr (P <= 16) {
+#pragma unroll
+        for (int t = 0; t < CNT; t++) {
+            const int s = (((S0 + t) % P) + P) % P;          // lane + s, 0 <= s < P
+            switch (s) {                                      // (a compile-time value once unrolled)
+                case 0: out[t] = v; break;
+                case 1: out[t] = w1d_row_ror<15>(v); break;
+                case 2: out[t] = w1d_row_ror<14>(v); break;
+                case 3: out[t] = w1d_row_ror<13>(v); break;
+                case 4: out[t] = w1d_row_ror<12>(v); break;
+                case 5: out[t] = w1d_row_ror<11>(v); break;
+                case 6: out[t] = w1d_row_ror<10>(v); break;
+                case 7: out[t] = w1d_row_ror<9>(v); break;
+                case 8: out[t] = w1d_row_ror<8>(v); break;
+                case 9: out[t] = w1d_row_ror<7>(v); break;
+                case 10: out[t] = w1d_row_ror<6>(v); break;
+                case 11: out[t] = w1d_row_ror<5>(v); break;
+                case 12: out[t] = w1d_row_ror<4>(v); break;
+                case 13: out[t] = w1d_row_ror<3>(v); break;
+                case 14: out[t] = w1d_row_ror<2>(v); break;
+                default: out[t] = w1d_row_ror<1>(v); break;
+            }
+        }
+    } else {
+        static_assert(S0 <= 0 && S0 + CNT - 1 >= 0 && -S0 < P / 2 && S0 + CNT - 1 <= P / 2, "distances around 0, below half a period");
+        out[-S0] = v;
+        double cur = v;
+#pragma unroll
+        for (int s = 1; s <= S0 + CNT - 1; s++) {
+            cur = w1d_rol1(cur);                              // lane + s
+            out[s - S0] = cur;
+        }
+        cur = v;
+#pragma unroll
+        for (int s = -1; s >= S0; s--) {
+            cur = w1d_ror1(cur);                              // lane - |s|
+            out[s - S0] = cur;
+        }
+    }
+}
+// floor(c / 2) for either sign
+__host__ __device__ constexpr int w1d_floor_half(int c) { return (c >= 0) ? c / 2 : -((1 - c) / 2); }
+
+// The taps' inputs of one level below 64 values, v[j] = in[(2 k + NP/2 - j) mod 2^(LG+1)] for the lane's output
+// k = lane mod 2^LG: `in` holds index lane mod 2^(LG+1).  The even and the odd inputs are gathered once each
+// (E[l] = in[2 l], O[l] = in[2 l + 1], two ds_bpermute pairs); with them a tap is a neighbour's value,
+// in[2 k + c] = E[k + c / 2] or O[k + (c - 1) / 2], reached by DPP moves (w1d_shifts) -- against one gather per tap.
+template <int NP, int LG>
+__device__ __forceinline__ void w1d_small_taps(double in, double* v, int lane) {
+    constexpr int P = 1 << LG;
+    const int src = 2 * (lane & (P - 1));
+    const double E = w1d_lane(in, src), O = w1d_lane(in, src + 1);
+    // c = NP/2 - j runs from NP/2 down to NP/2 - NP + 1
+    constexpr int CHI = NP / 2, CLO = NP / 2 - NP + 1;
+    constexpr int CEHI = (CHI % 2 == 0) ? CHI : CHI - 1, CELO = (CLO % 2 == 0) ? CLO : CLO + 1;     // even c
+    constexpr int COHI = (CHI % 2 != 0) ? CHI : CHI - 1, COLO = (CLO % 2 != 0) ? CLO : CLO + 1;     // odd c
+    constexpr int SE0 = w1d_floor_half(CELO), SE1 = w1d_floor_half(CEHI), SO0 = w1d_floor_half(COLO), SO1 = w1d_floor_half(COHI);
+    double Es[SE1 - SE0 + 1], Os[SO1 - SO0 + 1];
+    w1d_shifts<SE0, SE1 - SE0 + 1, P>(E, Es);
+    w1d_shifts<SO0, SO1 - SO0 + 1, P>(O, Os);
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        const int c = NP / 2 - j;
+        v[j] = (c % 2 == 0) ? Es[w1d_floor_half(c) - SE0] : Os[w1d_floor_half(c) - SO0];
+    }
+}
+
 // The lane's M values (own[M]) with HL values of the lanes before it and HR of the lanes after it in
 // ext[HL + M + HR]: ext[HL + i] = own[i]; ext[HL - 1 - t] and ext[HL + M + t] continue the sequence on either side.
 template <int M, int HL, int HR>
@@ -149,12 +231,16 @@ __device__ __forceinline__ void w1d_fwd_block(const double* in, double* lo, doub
 template <int NP, int LG>
 __device__ __forceinline__ void w1d_fwd_small(double in, double& lo, double& hi, const double (&a)[NP],
                                               const double (&b)[NP], int lane) {
+    double v[NP];   // the inputs first: they are independent, the sums are chains
+#ifdef WN_SMALL_LEVELS_BY_GATHER
     constexpr int half = 1 << LG;
     // source index 2k + N/2 - j modulo the length; any lane congruent to it holds the value
     const int base = 2 * (lane & (half - 1)) + 64 + NP / 2 - (NP - 1);
-    double v[NP];   // all gathers first: they are independent, the sums are chains
 #pragma unroll
     for (int j = 0; j < NP; j++) v[j] = w1d_lane(in, base + (NP - 1 - j));
+#else
+    w1d_small_taps<NP, LG>(in, v, lane);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     double sl = 0, sh = 0;
 #pragma unroll
@@ -222,11 +308,15 @@ __device__ __forceinline__ double w1d_bwd_small(double dlo, double dhi, double a
                                                 const double (&b)[NP], double (&gL)[NP], double (&gH)[NP], int lane) {
     constexpr int len = 1 << LG, alen = 2 * len;
     const double wl = lane < len ? dlo : 0.0, wh = lane < len ? dhi : 0.0;
-    const int gbase = 2 * (lane & (len - 1)) + 64 + NP / 2 - (NP - 1);
     {
         double v[NP];
+#ifdef WN_SMALL_LEVELS_BY_GATHER
+        const int gbase = 2 * (lane & (len - 1)) + 64 + NP / 2 - (NP - 1);
 #pragma unroll
         for (int u = 0; u < NP; u++) v[u] = w1d_lane(act, gbase + (NP - 1 - u));
+#else
+        w1d_small_taps<NP, LG>(act, v, lane);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < NP; u++) {
@@ -240,13 +330,21 @@ __device__ __forceinline__ double w1d_bwd_small(double dlo, double dhi, double a
     // Both parities are evaluated from one set of gathers and the lane keeps its own: indexing the
     // taps by the lane's parity would turn the tap arrays into memory.
     constexpr int CMIN = CE < CO ? CE : CO;
-    const int pbase = ((lane & (alen - 1)) >> 1) + 64 + CMIN;
     double vl[NP / 2 + 1], vh[NP / 2 + 1];
+#ifdef WN_SMALL_LEVELS_BY_GATHER
+    const int pbase = ((lane & (alen - 1)) >> 1) + 64 + CMIN;
 #pragma unroll
     for (int t = 0; t <= NP / 2; t++) {
         vl[t] = w1d_lane(dlo, pbase + t);
         vh[t] = w1d_lane(dhi, pbase + t);
     }
+#else
+    // Every lane works out both results of ITS error index p = lane mod 2^LG from its neighbours' errors (DPP moves);
+    // the lanes of the level above then fetch theirs, index m = lane mod 2^(LG+1), from lane m / 2: one gather each
+    // for the even and the odd result, against one per tap and array.
+    w1d_shifts<CMIN, NP / 2 + 1, len>(dlo, vl);
+    w1d_shifts<CMIN, NP / 2 + 1, len>(dhi, vh);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     double se = 0, so = 0;
 #pragma unroll
@@ -256,6 +354,11 @@ __device__ __forceinline__ double w1d_bwd_small(double dlo, double dhi, double a
         so = __builtin_fma(a[JO + 2 * i], vl[i + CO - CMIN], so);
         so = __builtin_fma(b[JO + 2 * i], vh[i + CO - CMIN], so);
     }
+#ifndef WN_SMALL_LEVELS_BY_GATHER
+    const int from = (lane & (alen - 1)) >> 1;
+    se = w1d_lane(se, from);
+    so = w1d_lane(so, from);
+#endif
     const double s = (lane & 1) ? so : se;
     return s;
 }
