@@ -71,6 +71,14 @@ __device__ __forceinline__ double w1d_row_ror(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// Permutation inside every group of four lanes: lane 4 g + i receives lane 4 g + {A, B, C, D}[i] (DPP quad_perm).
+template <int A, int B, int C, int D>
+__device__ __forceinline__ double w1d_quad(double v) {
+    constexpr int ctrl = A | (B << 2) | (C << 4) | (D << 6);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 // out[t] = v of lane (lane + S0 + t), t < CNT, for a value that is periodic in the lane number with period P (a
 // power of two up to 64).  Periods up to 16 repeat inside every row of 16 lanes, so one row rotation reaches any
 // distance; the longer periods are followed one lane at a time by rotations of the whole wave, outwards from
@@ -128,8 +136,18 @@ __host__ __device__ constexpr int w1d_floor_half(int c) { return (c >= 0) ? c / 
 template <int NP, int LG>
 __device__ __forceinline__ void w1d_small_taps(double in, double* v, int lane) {
     constexpr int P = 1 << LG;
-    const int src = 2 * (lane & (P - 1));
-    const double E = w1d_lane(in, src), O = w1d_lane(in, src + 1);
+    double E, O;
+    if constexpr (LG == 0) {             // two inputs, in lanes 0 and 1 of every four
+        E = w1d_quad<0, 0, 0, 0>(in);
+        O = w1d_quad<1, 1, 1, 1>(in);
+    } else if constexpr (LG == 1) {      // four inputs, one per lane of every four
+        E = w1d_quad<0, 2, 0, 2>(in);
+        O = w1d_quad<1, 3, 1, 3>(in);
+    } else {
+        const int src = 2 * (lane & (P - 1));
+        E = w1d_lane(in, src);
+        O = w1d_lane(in, src + 1);
+    }
     // c = NP/2 - j runs from NP/2 down to NP/2 - NP + 1
     constexpr int CHI = NP / 2, CLO = NP / 2 - NP + 1;
     constexpr int CEHI = (CHI % 2 == 0) ? CHI : CHI - 1, CELO = (CLO % 2 == 0) ? CLO : CLO + 1;     // even c
@@ -151,6 +169,24 @@ template <int M, int HL, int HR>
 __device__ __forceinline__ void w1d_extend(const double* own, double* ext, int lane) {
 #pragma unroll
     for (int i = 0; i < M; i++) ext[HL + i] = own[i];
+#ifndef WN_HALOS_BY_GATHER
+    // Every register is followed outwards one lane at a time (wave rotations, DPP moves in the vector pipeline):
+    // distance d is one more rotation of what distance d - 1 brought in.
+    double cur[M];
+#pragma unroll
+    for (int t = 0; t < HL; t++) {
+        const int d = 1 + t / M, reg = M - 1 - (t % M);
+        cur[reg] = w1d_ror1(d == 1 ? own[reg] : cur[reg]);
+        ext[HL - 1 - t] = cur[reg];
+    }
+#pragma unroll
+    for (int t = 0; t < HR; t++) {
+        const int d = 1 + t / M, reg = t % M;
+        cur[reg] = w1d_rol1(d == 1 ? own[reg] : cur[reg]);
+        ext[HL + M + t] = cur[reg];
+    }
+    (void)lane;
+#else
 #pragma unroll
     for (int t = 0; t < HL; t++) {
         const int d = 1 + t / M, reg = M - 1 - (t % M);
@@ -200,6 +236,7 @@ __device__ __forceinline__ void w1d_extend(const double* own, double* ext, int l
         }
         ext[HL + M + t] = v;
     }
+#endif
 }
 
 // ---- forward (src/Wavenet.cxx:404-445) ----------------------------------------------------------------
@@ -355,9 +392,14 @@ __device__ __forceinline__ double w1d_bwd_small(double dlo, double dhi, double a
         so = __builtin_fma(b[JO + 2 * i], vh[i + CO - CMIN], so);
     }
 #ifndef WN_SMALL_LEVELS_BY_GATHER
-    const int from = (lane & (alen - 1)) >> 1;
-    se = w1d_lane(se, from);
-    so = w1d_lane(so, from);
+    if constexpr (LG == 1) {             // two error indices: lanes 0, 1 of every four hold them
+        se = w1d_quad<0, 0, 1, 1>(se);
+        so = w1d_quad<0, 0, 1, 1>(so);
+    } else if constexpr (LG > 1) {
+        const int from = (lane & (alen - 1)) >> 1;
+        se = w1d_lane(se, from);
+        so = w1d_lane(so, from);
+    }                                    // (LG == 0: one error index, the same results in every lane)
 #endif
     const double s = (lane & 1) ? so : se;
     return s;
