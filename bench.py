@@ -268,7 +268,7 @@ def run_workload(name, args, rank, local_rank, world, dist):
     final_filter = ctx.filter()
     # the same number of steps on ONE resident batch, which the Infinity Cache can hold on to: does the time move?
     single_ms = None
-    if nrot > 1 and world == 1:
+    if nrot > 1 and world == 1 and not args.no_single_batch:
         single_ms = timed(args.steps, False)[1]
     # What every rank of a multi-GPU run pays on the serial path of a batch, measured on this one GPU: the step as
     # three submissions with a one-rank RCCL all-reduce of the sums in the middle against the fused single submission.
@@ -350,6 +350,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rotate", type=int, default=0, help="distinct resident batches the steps rotate over (default: per workload)")
     ap.add_argument("--no-exchange-probe", action="store_true", help="skip the split-step / one-rank all-reduce timing of the headline")
+    ap.add_argument("--no-single-batch", action="store_true", help="skip the extra timing loop on one resident batch (counter passes: every step of the run is then a rotating one)")
     ap.add_argument("--no-coach-probe", action="store_true", help="skip the C++ Coach::run timing of the headline")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="scales the seconds spent on the CPU baselines")
     ap.add_argument("--dry-run", action="store_true", help="print what each rank would run (no GPU is touched)")

@@ -14,8 +14,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GO = os.path.join(ROOT, "gpurun_out")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-WORKLOADS = ["2d64", "2d64n16", "1d1024", "2d512", "1d1m"]
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+WORKLOADS = ["2d64", "2d64n16", "1d1024", "2d512", "2d512n16", "1d1m", "1d1mb64"]
 PMC_STEPS = 6          # tools/pmc_workload.sh runs bench.py with 5 timed steps and 1 warm-up step
 # kernels that are not part of a training step (input generation, torch's fills, copies of the set-up)
 NOT_STEP = ("kg_", "at::native", "k_reset_steps")
@@ -24,7 +24,7 @@ NOT_STEP = ("kg_", "at::native", "k_reset_steps")
 # kernels whose reads are 16-byte-per-lane streaming loads: FETCH_SIZE reports half of their bytes on gfx950
 # (checked here against their known input volumes: kr_fwd_rows, kc_fwd_cols and kr_hist each read the 4295 MB of
 # a 512x512 chunk once and report 2147 - 2212 MB)
-WIDE_READS = ("kr_fwd_rows", "kr_grad_rows", "kc_fwd_cols", "kc_bwd_cols", "kr_hist", "kr_part", "kr_max", "k_train1d1024")
+WIDE_READS = ("kr_fwd_rows", "kr_grad_rows", "kc_fwd_cols", "kc_bwd_cols", "kr_hist", "kr_part", "kr_count", "kr_max", "k_train1d1024")
 
 
 def step_bytes(path, counter):

@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {
   local name=$1; shift
   rm -rf /tmp/pmc_$name
-  timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$name -o r -- python $ROOT/bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_${W}_$name.err || { echo "pass $name failed"; tail -5 $OUT/${TAG}_${W}_$name.err; exit 1; }
+  timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pmc_$name -o r -- python $ROOT/bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline --no-single-batch --no-exchange-probe --no-coach-probe > /dev/null 2> $OUT/${TAG}_${W}_$name.err || { echo "pass $name failed"; tail -5 $OUT/${TAG}_${W}_$name.err; exit 1; }
   cp $(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1) $OUT/${TAG}_${W}_$name.csv
   echo "pass $name done"
 }

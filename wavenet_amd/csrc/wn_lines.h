@@ -334,8 +334,11 @@ __global__ __launch_bounds__(LN_HIST_T) void kc_fwd_cols_hist(const double* __re
 // errors is then never written.
 // ranks: per slice of `slice` examples an array of slice * n ranks at ranks + slice_first_example * n
 // DOUBLES (the streamed path's layout).
+#ifndef LN_BWD_COLS_WAVES
+#define LN_BWD_COLS_WAVES 2
+#endif
 template <int NP, int M, bool FROM_RANKS>
-__global__ LN_BOUNDS(256) void kc_bwd_cols(const double* __restrict__ coef, const double* __restrict__ in, double* __restrict__ out,
+__global__ __launch_bounds__(256, (NP >= LN_ONE_WAVE_FROM ? 1 : LN_BWD_COLS_WAVES)) void kc_bwd_cols(const double* __restrict__ coef, const double* __restrict__ in, double* __restrict__ out,
                                            size_t xs, int ncols, const FilterDev* filt, double* partial, const double* ranks,
                                            int slice, const double* fg) {
     // four independent waves per workgroup, each with a partial-sum slot of its own (grid.x * 4 <= LN_GX)
