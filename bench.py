@@ -262,7 +262,7 @@ def run_workload(name, args, rank, local_rank, world, dist):
     # context runs on torch's current stream)
     elapsed, device_ms = timed(args.steps, True)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_filter = ctx.filter()
@@ -354,6 +354,9 @@ def main():
     ap.add_argument("--no-coach-probe", action="store_true", help="skip the C++ Coach::run timing of the headline")
     ap.add_argument("--cpu-scale", type=float, default=1.0, help="scales the seconds spent on the CPU baselines")
     ap.add_argument("--dry-run", action="store_true", help="print what each rank would run (no GPU is touched)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="several ranks on ONE GPU (every rank on device 0, sums exchanged by gloo): the multi-rank code path "
+                         "of this script where only one GPU is at hand; the rate it prints is not a scaling measurement")
     args = ap.parse_args()
 
     from wavenet_amd.parallel import dist_env, shard_range
@@ -376,15 +379,21 @@ def main():
         print(json.dumps({"rank": rank, "world": world, "scaling": args.scaling, "plan": plan}), flush=True)
         return
     import torch
-    torch.cuda.set_device(local_rank)
+    device_index = 0 if args.rehearse else local_rank
+    torch.cuda.set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
 
     for name in workload_names(args, world):
-        line = run_workload(name, args, rank, local_rank, world, dist)
+        line = run_workload(name, args, rank, device_index, world, dist)
         if rank == 0:
+            if args.rehearse:
+                line["rehearsal"] = f"{world} ranks on one GPU, gloo exchange: not a scaling measurement"
             print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -26,7 +26,14 @@ def allreduce_sums(sums, world_size, group=None):
     """In-place sum over ranks of the per-rank sums tensor (any device torch.distributed supports)."""
     if world_size > 1:
         import torch.distributed as dist
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        if sums.is_cuda and dist.get_backend(group) == "gloo":
+            # gloo reduces host memory: over the host and back, in stream order (the copy out waits for the kernels
+            # that wrote the sums, the copy back is queued before whatever reads them)
+            host = sums.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            sums.copy_(host)
+        else:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
     return sums
 
 
