@@ -423,7 +423,8 @@ def test_bucket_ranking(oracle, capfd, monkeypatch, n, B):
         radix.close()
 
 
-@pytest.mark.parametrize("R,C,N,B", [(128, 128, 4, 300), (256, 128, 8, 260), (128, 512, 2, 256), (512, 512, 4, 256)])
+@pytest.mark.parametrize("R,C,N,B", [(128, 128, 4, 300), (256, 128, 8, 260), (128, 512, 2, 256), (512, 512, 4, 256),
+                                     (1024, 128, 4, 256), (256, 256, 16, 256)])
 def test_histograms_built_by_the_column_kernel(oracle, R, C, N, B):
     """With an example per CU or more and both passes on the line kernels, the column kernel leaves the ranking's
     histograms and largest magnitudes itself (kc_fwd_cols_hist) instead of kr_hist reading the coefficients
@@ -431,7 +432,7 @@ def test_histograms_built_by_the_column_kernel(oracle, R, C, N, B):
     path with WAVENET_HIP_FUSED_HIST=0; two examples are checked against the oracle.  Examples scaled by 1e-30 and
     1e30 sit far from the others' magnitudes; in the second batch the taps are scaled by 1e4, which puts the
     kernel's bound on the largest magnitude so far above the truth that it hands every example to kr_hist; a NaN
-    in one example goes the same way."""
+    in one example goes the same way, and an image of zeros has nothing to count."""
     import torch
     from wavenet_amd import generators as G
     a = filt_for(N, 2)
@@ -457,6 +458,7 @@ def test_histograms_built_by_the_column_kernel(oracle, R, C, N, B):
             assert out["fused"][2][e] == pytest.approx(se, rel=1e-11)
         # the bound too far above the truth, and a non-finite example
         X[5, 3, 2] = np.nan
+        X[7] = 0.0                 # and an image of zeros: no magnitude to count, no largest one
         dX = to_dev(X)
         for name, c in (("fused", fused), ("plain", plain)):
             c.set_filter(1e4 * a)
