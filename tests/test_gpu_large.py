@@ -472,3 +472,60 @@ def test_histograms_built_by_the_column_kernel(oracle, R, C, N, B):
         torch.cuda.synchronize()
         fused.close()
         plain.close()
+
+
+def test_full_batch_of_512x512_against_its_parts(ctx):
+    """The bench's full batch -- 2048 images of 512x512 (one GPU's share of the 16384-image configuration), generated
+    on the device -- against the same images handed over in eight parts of 256: every per-example cost and gradient
+    is the same bit for bit (an example's result does not depend on its neighbours in the batch, on the chunking of
+    the workspace or on which kernel built its histogram), the batch sums agree to rounding, nothing is non-finite,
+    and the sparsity costs lie in (0, 1)."""
+    import torch
+    R = C = 512
+    N, B, part = 4, 2048, 256
+    n = R * C
+    ctx.set_filter(filt_for(N, 5))
+    dX = torch.empty(B * n, dtype=torch.float64, device="cuda")
+    ctx.generate_calorimeter(dX, B, R, C, seed=1000, first=0)
+    dG, dS = dev_empty(B * N), dev_empty(B)
+    ctx.train_batch(dX, B, R, C, dG, dS)
+    sums = ctx.sums().copy()
+    G1, S1 = dG.cpu().numpy().copy(), dS.cpu().numpy().copy()
+    dG2, dS2 = dev_empty(B * N), dev_empty(B)
+    acc = np.zeros_like(sums)
+    for e0 in range(0, B, part):
+        ctx.train_batch(dX[e0 * n:], part, R, C, dG2[e0 * N:], dS2[e0:])
+        acc += ctx.sums()
+    assert np.array_equal(G1, dG2.cpu().numpy())
+    assert np.array_equal(S1, dS2.cpu().numpy())
+    assert sums[-1] == 0 and acc[-1] == 0
+    assert relerr(sums[:-1], acc[:-1]) < 1e-12
+    assert np.all((S1 > 0) & (S1 < 1))
+    assert sums[N] == pytest.approx(S1.sum(), rel=1e-12)
+    del dX
+    torch.cuda.empty_cache()
+
+
+def test_batch_of_long_signals_against_its_parts(ctx):
+    """Eight signals of 2^20 samples with 32 taps (one GPU's share of the 64-signal configuration) against the same
+    signals one at a time: several workgroups share an example in the ranking there, one alone here."""
+    import torch
+    from wavenet_amd import generators as G
+    n, N, B = 1 << 20, 32, 8
+    ctx.set_filter(filt_for(N, 3))
+    X = G.bumps(B, n, seed=1000).reshape(B, n, 1)
+    dX = to_dev(X)
+    dG, dS = dev_empty(B * N), dev_empty(B)
+    ctx.train_batch(dX, B, n, 1, dG, dS)
+    sums = ctx.sums().copy()
+    G1, S1 = dG.cpu().numpy().copy(), dS.cpu().numpy().copy()
+    dG2, dS2 = dev_empty(B * N), dev_empty(B)
+    acc = np.zeros_like(sums)
+    for e in range(B):
+        ctx.train_batch(dX[e * n:], 1, n, 1, dG2[e * N:], dS2[e:])
+        acc += ctx.sums()
+    assert np.array_equal(S1, dS2.cpu().numpy())
+    assert relerr(G1.reshape(B, N), dG2.cpu().numpy().reshape(B, N)) < 1e-12
+    assert sums[-1] == 0
+    assert relerr(sums[:-1], acc[:-1]) < 1e-12
+    assert np.all((S1 > 0) & (S1 < 1))
