@@ -112,6 +112,15 @@ int main(int argc, char** argv) {
         dump("refused", flags, 3);
         return 0;
     }
+    if (mode == "sparse") {     // sparse n file: the free functions on a vector of any length
+        const size_t n = (size_t)std::atoll(argv[2]);
+        std::vector<double> in = readAll(argv[3]);
+        const Col c(n, in.data());
+        const double s = SparseTerm(c);
+        dump("sparse", &s, 1);
+        dump("sparseDeriv", SparseTermDeriv(c));
+        return 0;
+    }
     if (mode == "train") {
         const unsigned R = std::atoi(argv[2]), C = std::atoi(argv[3]), N = std::atoi(argv[4]), E = std::atoi(argv[5]);
         const unsigned batch = std::atoi(argv[6]);

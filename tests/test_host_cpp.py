@@ -171,6 +171,21 @@ def test_data_parallel_coach_is_shard_invariant(oracle, flags, events, batch):
         assert np.allclose(cl, w.cost_log(), rtol=1e-9, atol=1e-15)
 
 
+@pytest.mark.parametrize("n", [1, 3, 5, 100, 1000, 4097, 6000, 8192, 70000])
+def test_sparse_term_of_any_length(oracle, n):
+    """The reference's SparseTerm / SparseTermDeriv take vectors of any length (src/CostFunctions.cxx:6-117); the
+    device kernels take powers of two, so the host layer pads with zeros and undoes what the padding does to the
+    two sums.  Exact zeros inside the vector and a length of one included."""
+    rng = np.random.default_rng(n)
+    c = rng.standard_normal(n) * np.exp(3 * rng.standard_normal(n))
+    if n > 4:
+        c[rng.integers(0, n, size=n // 7)] = 0.0
+    out, _ = run_driver(["sparse", n], [c])
+    assert out["sparse"][0] == pytest.approx(oracle.sparse_term(c), rel=1e-11, abs=1e-13)
+    want = np.asarray(oracle.sparse_term_deriv(c))
+    assert np.allclose(out["sparseDeriv"], want, rtol=1e-10, atol=1e-12 * max(1e-300, np.abs(want).max()))
+
+
 def _gpu_count():
     import torch
     return torch.cuda.device_count()      # counting devices does not initialise the GPU

@@ -1,7 +1,9 @@
 #include "Wavenet/CostFunctions.h"
 
+#include <algorithm>
 #include <cmath>
 #include <limits>
+#include <vector>
 
 #include "Wavenet/Logger.h"
 #include "Wavenet/Utilities.h"
@@ -27,17 +29,42 @@ struct SharedBuffers {
     std::size_t capacity = 0;
 };
 
+double sparseOnDevice(const double* c, std::size_t n, double* delta);
+
+// A length that is not a power of two (the reference takes any, src/CostFunctions.cxx:6-46): the vector goes to the
+// device behind p zeros that fill it up to n' = 2^k.  Zeros rank first and carry no weight, so the padded sums are
+// f' = f + p sum|c| and g' = n' sum|c|, from which the true values follow without sum|c|:
+//   S = 1 - ((1 - S') n' - p) / n,     delta_j = delta'_j n' / n.
+double sparsePadded(const double* c, std::size_t n, double* delta) {
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    if (n == 0) return nan;
+    std::size_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    static std::vector<double> in, out;
+    in.assign(np2, 0.0);
+    std::copy(c, c + n, in.begin());
+    if (delta) out.resize(np2);
+    const double Sp = sparseOnDevice(in.data(), np2, delta ? out.data() : nullptr);
+    if (!(Sp == Sp)) return nan;
+    const double scale = (double)np2 / (double)n;
+    if (delta) {
+        for (std::size_t j = 0; j < n; j++) delta[j] = out[j] * scale;
+    }
+    return 1.0 - ((1.0 - Sp) * (double)np2 - (double)(np2 - n)) / (double)n;
+}
+
 // Runs SparseTerm / SparseTermDeriv on n values (any radix-2 length the library takes: the streamed ranking beyond
-// WN_MAX_FUSED coefficients); delta may be null.  NaN on failure.
+// WN_MAX_FUSED coefficients; other lengths zero-padded, see above); delta may be null.  NaN on failure.
 double sparseOnDevice(const double* c, std::size_t n, double* delta) {
     const double nan = std::numeric_limits<double>::quiet_NaN();
     static SharedBuffers buf;
     wn_context* ctx = sharedContext();
     if (!ctx) return nan;
-    if (!isRadix2((unsigned)n) || n > ((std::size_t)1 << 30)) {
-        ERROR("SparseTerm on %zu coefficients is not supported (radix 2, at most 2^30).", n);
+    if (n > ((std::size_t)1 << 30)) {
+        ERROR("SparseTerm on %zu coefficients is not supported (at most 2^30).", n);
         return nan;
     }
+    if (!isRadix2((unsigned)n)) return sparsePadded(c, n, delta);
     if (buf.capacity < n) {
         if (buf.Y) wn_free(ctx, buf.Y);
         if (buf.D) wn_free(ctx, buf.D);
