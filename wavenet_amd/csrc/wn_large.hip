@@ -536,26 +536,28 @@ __global__ __launch_bounds__(256) void kb_grad_finish(const double* partial, int
 // sums[0..N) += sum_e grad_e, sums[N] += sum_e S_e, sums[N+1] += number of non-finite values.  One wave per
 // quantity (grid N + 2): lane l adds examples l, l + 64, ... in order, the lanes are combined by a
 // butterfly -- a fixed order.
-__global__ __launch_bounds__(64) void kb_batch_sums(const double* grad_e, const double* S_e, int B, int N, double* sums, int first,
-                                                    const unsigned* skip) {
-    const int t = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void kb_batch_sums(const double* grad_e, const double* S_e, int B, int N, double* sums, int first,
+                                                     const unsigned* skip) {
+    __shared__ double red[4];
+    const int t = blockIdx.x, tid = threadIdx.x;
     if (t > N + 1) return;
     if (skip && *skip) return;   // the chunk is going to be computed again (see train_impl): leave the sums alone
     double s = 0;
     if (t < N) {
-        for (int e = lane; e < B; e += 64) s += grad_e[(size_t)e * N + t];
+        for (int e = tid; e < B; e += 256) s += grad_e[(size_t)e * N + t];
     } else if (t == N) {
-        for (int e = lane; e < B; e += 64) s += S_e[e];
+        for (int e = tid; e < B; e += 256) s += S_e[e];
     } else {
-        for (int e = lane; e < B; e += 64) {
-            if (!isfinite(S_e[e])) s += 1;
-            for (int k = 0; k < N; k++) {
-                if (!isfinite(grad_e[(size_t)e * N + k])) s += 1;
-            }
+        for (int e = tid; e < B; e += 256) {
+            int bad = isfinite(S_e[e]) ? 0 : 1;
+            for (int k = 0; k < N; k++) bad += isfinite(grad_e[(size_t)e * N + k]) ? 0 : 1;
+            s += (double)bad;
         }
     }
     s = wave_sum(s);
-    if (lane == 0) sums[t] = (first ? 0.0 : sums[t]) + s;
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) sums[t] = (first ? 0.0 : sums[t]) + (((red[0] + red[1]) + red[2]) + red[3]);   // a fixed order
 }
 
 // ---- Gini --------------------------------------------------------------------------------------------
@@ -1415,7 +1417,7 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
             }
         }
         hipLaunchKernelGGL(kb_grad_finish, dim3(Bc), dim3(256), 0, st, pl.partial, NP, ctx->dfilt, grad_e, pgx);
-        hipLaunchKernelGGL(kb_batch_sums, dim3(N + 2), dim3(64), 0, st, grad_e, S_e, Bc, N, ctx->sums, e0 == 0 ? 1 : 0, *pending);
+        hipLaunchKernelGGL(kb_batch_sums, dim3(N + 2), dim3(256), 0, st, grad_e, S_e, Bc, N, ctx->sums, e0 == 0 ? 1 : 0, *pending);
         WN_HIP(ctx, hipGetLastError());
         return WN_OK;
     };

@@ -7,8 +7,8 @@
 //                fixed, counted down from the example's largest magnitude, whose exponent word the producer
 //                of the coefficients left in kmax), built in LDS;
 //   2. kr_scan   prefix sums of the histogram; consecutive bins are grouped into buckets by cutting the sorted
-//                order every RK_T positions (bucket of a bin = its first sorted position / RK_T), so a bucket
-//                holds fewer than RK_T + (largest bin) magnitudes;
+//                order every T positions (bucket of a bin = its first sorted position / T), so a bucket
+//                holds fewer than T + (largest bin) magnitudes; T = RK_CAP - (the example's largest bin), at least RK_T;
 //   3. kr_part   every non-zero magnitude, with its home index, goes to its bucket's range of a staging array
 //                (order inside the bucket: as it comes);
 //   4. kr_bucket one workgroup per bucket: a counting sort in LDS over 4096 sub-bins that split the bucket's
@@ -201,28 +201,82 @@ __global__ __launch_bounds__(RK_BT) void kr_scan(const unsigned* __restrict__ hi
     const int per = NF / RK_BT;                   // consecutive bins per thread (NF is a multiple of RK_BT)
     unsigned loc[RK_NFMAX / RK_BT];
     unsigned sum = 0;
+    if (per % 4 == 0) {      // the thread's bins are consecutive words: 16-byte loads
+        const uint4* h4 = reinterpret_cast<const uint4*>(h + tid * per);
 #pragma unroll
-    for (int k = 0; k < RK_NFMAX / RK_BT; k++) {
-        loc[k] = (k < per) ? h[tid * per + k] : 0u;
-        sum += loc[k];
+        for (int q = 0; q < RK_NFMAX / RK_BT / 4; q++) {
+            const uint4 v = (q < per / 4) ? h4[q] : make_uint4(0u, 0u, 0u, 0u);
+            loc[4 * q] = v.x; loc[4 * q + 1] = v.y; loc[4 * q + 2] = v.z; loc[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < RK_NFMAX / RK_BT; k++) loc[k] = (k < per) ? h[tid * per + k] : 0u;
     }
+#pragma unroll
+    for (int k = 0; k < RK_NFMAX / RK_BT; k++) sum += loc[k];
     unsigned nz;
     unsigned run = block_exclusive_scan(sum, wsum, &nz);
 #pragma unroll
     for (int k = 0; k < RK_NFMAX / RK_BT; k++) {
         if (k < per) { rk_c[tid * per + k] = run; run += loc[k]; }
     }
+    // Sorted positions per bucket for THIS example: a bucket holds fewer than T + (largest bin) magnitudes, so with
+    // T = RK_CAP - largest bin it is as full as it can safely be (94 - 98 % for bins of a few hundred; RK_T, 75 %, is
+    // the floor, below which the number of buckets would outgrow the tables: an example with a bin of more than
+    // RK_CAP - RK_T magnitudes is cut as before, and raises the flag if a bucket then overflows).
+    unsigned big = 0;
+#pragma unroll
+    for (int k = 0; k < RK_NFMAX / RK_BT; k++) big = max(big, loc[k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) big = max(big, (unsigned)__shfl_xor((int)big, o, 64));
+    __shared__ unsigned wbig[RK_BT / 64];
+    if ((tid & 63) == 0) wbig[tid >> 6] = big;
     for (int b = tid; b <= nbmax; b += RK_BT) { bs[b] = nz; bf0[b] = (unsigned)NF; }
     __syncthreads();
+#pragma unroll
+    for (int w = 0; w < RK_BT / 64; w++) big = max(big, wbig[w]);
+    const unsigned T = max((unsigned)RK_T, (unsigned)RK_CAP - min(big, (unsigned)RK_CAP));
     unsigned short* bt = btab + (size_t)e * NF;
-    for (int f = tid; f < NF; f += RK_BT) {
-        const int bf = (int)(rk_c[f] / RK_T);
-        const int bprev = f ? (int)(rk_c[f - 1] / RK_T) : -1;
-        for (int b = bprev + 1; b <= bf; b++) { bs[b] = rk_c[f]; bf0[b] = (unsigned)f; }   // the first bin that starts in bucket b's range
-        bt[f] = (unsigned short)bf;
+    {
+        // The thread's own `per` consecutive bins: first sorted positions from registers, position / T by a multiplication
+        // with 1 / T and one correction either way (positions are below 2^22, quotients below 2^10), the bucket numbers
+        // stored 16 bytes at a time.
+        const float invT = 1.0f / (float)T;
+        auto bucket_of = [&](unsigned pos) -> int {
+            unsigned q = (unsigned)((float)pos * invT);
+            if (q * T > pos) q--;
+            if ((q + 1u) * T <= pos) q++;
+            return (int)q;
+        };
+        const int f0 = tid * per;
+        unsigned pos = f0 ? rk_c[f0] : 0u;
+        int bprev = f0 ? bucket_of(rk_c[f0 - 1]) : -1;
+        unsigned packed[RK_NFMAX / RK_BT / 2];
+#pragma unroll
+        for (int k = 0; k < RK_NFMAX / RK_BT; k++) {
+            if (k < per) {
+                const int bf = bucket_of(pos);
+                for (int b = bprev + 1; b <= bf; b++) { bs[b] = pos; bf0[b] = (unsigned)(f0 + k); }   // the first bin that starts in bucket b's range
+                if (k & 1) packed[k / 2] |= (unsigned)bf << 16; else packed[k / 2] = (unsigned)bf;
+                bprev = bf;
+                pos += loc[k];
+            }
+        }
+        if (per % 8 == 0) {
+            uint4* out = reinterpret_cast<uint4*>(bt + f0);
+#pragma unroll
+            for (int q = 0; q < RK_NFMAX / RK_BT / 8; q++) {
+                if (q < per / 8) out[q] = make_uint4(packed[4 * q], packed[4 * q + 1], packed[4 * q + 2], packed[4 * q + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < RK_NFMAX / RK_BT; k++) {
+                if (k < per) bt[f0 + k] = (unsigned short)((packed[k / 2] >> (16 * (k & 1))) & 0xFFFFu);
+            }
+        }
     }
     __syncthreads();
-    const int nb = nz ? (int)((nz - 1) / RK_T) + 1 : 0;
+    const int nb = nz ? (int)((nz - 1) / T) + 1 : 0;
     bool over = false;
     for (int b = tid; b <= nbmax; b += RK_BT) {
         meta_bstart(meta)[b] = bs[b];
