@@ -1274,7 +1274,7 @@ int make_plan(wn_context* ctx, int B, size_t n, int NP, int N, Plan* pl) {
         pl->idxA = c.take<unsigned>(Bc * n);
         pl->idxB = c.take<unsigned>(Bc * n);
         pl->cnt = c.take<unsigned>(Bc * (n / CP_BLOCK + 1) + 3 * Bc + 64);
-        pl->kmax = c.take<unsigned>(3 * Bc + 16);   // kmax[Bc], 16 spare words, then kc_fwd_cols_hist's bound inputs [Bc] and marks [Bc]
+        pl->kmax = c.take<unsigned>(2 * Bc + 16);   // kmax[Bc], 16 spare words, then kc_fwd_cols_hist's marks [Bc]
         pl->gpart = c.take<double>(Bc * GXMAX * 2);
         pl->fg = c.take<double>(Bc * 2);
         pl->partial = c.take<double>(Bc * (size_t)pgx * 2 * NP);
@@ -1331,8 +1331,11 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         rank_bins(n, &NF, &lgBPO);
         const bool fusedHist = rowLines && colLines && buckets && !forward_only && !pcolArg && ctx->fused_hist && n >= 8192 &&
                                Bc >= ctx->numCU && NF <= LN_HIST_BINS;
-        unsigned* kmaxRows = fusedHist ? pl.kmax + Bc + 16 : nullptr;
-        unsigned* histNeed = fusedHist ? pl.kmax + 2 * (size_t)Bc + 16 : nullptr;
+        // (the row kernel's per-wave maxima sit in the index array of the ranking, which is idle until the coefficients exist)
+        const int rowGroups = std::min(R / line_tile_rows(Mrow), LN_GX);
+        int rowParts = 4 * rowGroups;
+        unsigned* kmaxRows = fusedHist ? pl.idxA : nullptr;
+        unsigned* histNeed = fusedHist ? pl.kmax + (size_t)Bc + 16 : nullptr;
         size_t xs = n;
         int ncols = C, nrows = R;
         const FilterDev* dfilt = ctx->dfilt;
@@ -1346,9 +1349,9 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
             // LDS beyond the default limit
             WN_HIP(ctx, hipFuncSetAttribute(fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_tile_bytes(Mrow)));
             WN_HIP(ctx, hipFuncSetAttribute(grd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)line_tile_bytes(Mrow)));
-            if (fusedHist) WN_HIP(ctx, hipMemsetAsync(pl.kmax, 0, (size_t)(3 * Bc + 16) * sizeof(unsigned), st));   // the ranking's flag among them
+            if (fusedHist) WN_HIP(ctx, hipMemsetAsync(pl.kmax, 0, (size_t)(2 * Bc + 16) * sizeof(unsigned), st));   // the ranking's flag among them
             void* args[] = {(void*)&Xc, (void*)&Y1, (void*)&xs, (void*)&nrows, (void*)&dfilt, (void*)&kmaxRows};
-            WN_HIP(ctx, hipLaunchKernel(fwd, dim3(std::min(R / line_tile_rows(Mrow), LN_GX), Bc), dim3(256), args, line_tile_bytes(Mrow), st));
+            WN_HIP(ctx, hipLaunchKernel(fwd, dim3(rowGroups, Bc), dim3(256), args, line_tile_bytes(Mrow), st));
         } else if ((rc = fwd_pass_big<NP>(ctx, Xc, Prow, Y1, Bc, n, rg))) {
             return rc;
         }
@@ -1358,7 +1361,7 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
             unsigned* hist = pl.idxB;      // where gini_buckets expects them
             unsigned* kmaxOut = pl.kmax;
             WN_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LN_HIST_BINS * 4));
-            void* args[] = {(void*)&y1c, (void*)&YD, (void*)&xs, (void*)&ncols, (void*)&dfilt, (void*)&kmaxRows, (void*)&kmaxOut,
+            void* args[] = {(void*)&y1c, (void*)&YD, (void*)&xs, (void*)&ncols, (void*)&dfilt, (void*)&kmaxRows, (void*)&rowParts, (void*)&kmaxOut,
                             (void*)&histNeed, (void*)&hist, (void*)&NF, (void*)&lgBPO};
             WN_HIP(ctx, hipLaunchKernel(fn, dim3(Bc), dim3(LN_HIST_T), args, (size_t)LN_HIST_BINS * 4, st));
         } else if (colLines) {

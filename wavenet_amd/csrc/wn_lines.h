@@ -241,8 +241,8 @@ __global__ LN_BOUNDS(256) void kc_fwd_cols(const double* __restrict__ in, double
 // bins (wn_rank.h: fine_bin, counted down from the example's largest magnitude) and that largest magnitude's
 // exponent word -- what kr_max and kr_hist would otherwise read the coefficients back for.
 // The largest magnitude is only known at the end, so the workgroup counts over LN_HIST_BINS bins in LDS counted
-// down from a bound that is known beforehand: the largest exponent word of the input (kmax_in, left by the kernel
-// that wrote the input) raised by LEVELS * log2(max(1, sum |a_j|, sum |b_j|)) octaves and one more.  Both
+// down from a bound that is known beforehand: the largest exponent word of the input (the maximum of the nparts
+// words per example in kmax_in, left by the waves of the kernel that wrote the input) raised by LEVELS * log2(max(1, sum |a_j|, sum |b_j|)) octaves and one more.  Both
 // binnings cut the same absolute grid (exponent word >> shift), so the histogram below the true maximum is the
 // LDS one moved by (bound - maximum) bins, exactly.  When the bound lies more than LN_HIST_BINS - NF bins above
 // the maximum (or anything exceeds it: non-finite values), need[example] is set instead and kr_hist does that
@@ -251,7 +251,7 @@ constexpr int LN_HIST_T = 1024;
 constexpr int LN_HIST_BINS = 36864;
 template <int NP, int M>
 __global__ __launch_bounds__(LN_HIST_T) void kc_fwd_cols_hist(const double* __restrict__ in, double* __restrict__ Y, size_t xs, int ncols,
-                                                              const FilterDev* filt, const unsigned* __restrict__ kmax_in,
+                                                              const FilterDev* filt, const unsigned* __restrict__ kmax_in, int nparts,
                                                               unsigned* kmax, unsigned* need, unsigned* hist, int NF, int lgBPO) {
     constexpr int LEVELS = 6 + (M == 2 ? 1 : M == 4 ? 2 : M == 8 ? 3 : 4);
     extern __shared__ unsigned ln_hist[];
@@ -269,13 +269,22 @@ __global__ __launch_bounds__(LN_HIST_T) void kc_fwd_cols_hist(const double* __re
     const double octs = ceil((double)LEVELS * log2(gain) + 1e-6) + 1.0;
     const int shift = 20 - lgBPO;
     unsigned badv = 0;
+    // the largest exponent word of the input: the maximum over the words its producer's waves left
+    unsigned kin = 0;
+    for (int i = tid; i < nparts; i += LN_HIST_T) kin = max(kin, kmax_in[(size_t)e * nparts + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kin = max(kin, (unsigned)__shfl_xor((int)kin, o, 64));
+    if (lane0 == 0) wred[wave] = kin;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < LN_HIST_T / 64; w++) kin = max(kin, wred[w]);
     unsigned kprov = 0x7FEFFFFFu;
     if (octs < 1024.0) {
-        const unsigned long long kp = (unsigned long long)kmax_in[e] + ((unsigned long long)octs << 20);
+        const unsigned long long kp = (unsigned long long)kin + ((unsigned long long)octs << 20);
         if (kp < 0x7FF00000ull) kprov = (unsigned)kp;
     }
     const unsigned Lprov = kprov >> shift;
-    __syncthreads();
+    __syncthreads();                      // (wred is written again at the end)
     unsigned kmine = 0;
     const size_t off = (size_t)e * xs;
     for (int c = wave; c < ncols; c += LN_HIST_T / 64) {
@@ -484,7 +493,8 @@ __device__ __forceinline__ void ln_row_load(const double* row, LineLane<M>& y, i
 }
 
 // Forward over the rows: grid (tiles per example <= R / ROWS, examples), 256 threads, LineTile<M>::BYTES of LDS.
-// kmax_out (may be null): kmax_out[example] is raised to the largest exponent word among the example's row coefficients.
+// kmax_out (may be null): kmax_out[(example * workgroups per example + workgroup) * 4 + wave] receives the largest
+// exponent word among the row coefficients the wave produced.
 template <int NP, int M>
 __global__ LN_BOUNDS(256) void kr_fwd_rows(const double* __restrict__ in, double* __restrict__ Y, size_t xs, int R,
                                            const FilterDev* filt, unsigned* kmax_out) {
@@ -516,20 +526,10 @@ __global__ LN_BOUNDS(256) void kr_fwd_rows(const double* __restrict__ in, double
         ln_move_tile<M, false>(ln_tile, Y + base, R, tid);
     }
     if (kmax_out) {
+        // one word per wave, a plain store: no barrier and no atomic at the end of 65536 workgroups
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) kmine = max(kmine, (unsigned)__shfl_xor((int)kmine, o, 64));
-#ifndef LN_KMAX_PER_WAVE
-        __syncthreads();                    // the tile is free: one atomic per workgroup
-        unsigned* red = reinterpret_cast<unsigned*>(ln_tile);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = kmine;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            kmine = max(max(red[0], red[1]), max(red[2], red[3]));
-            if (kmine) atomicMax(&kmax_out[blockIdx.y], kmine);
-        }
-#else
-        if ((threadIdx.x & 63) == 0 && kmine) atomicMax(&kmax_out[blockIdx.y], kmine);
-#endif
+        if ((threadIdx.x & 63) == 0) kmax_out[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = kmine;
     }
 }
 
