@@ -32,6 +32,9 @@ struct wn_context {
     bool rank_configured = false;   // the ranking kernels' LDS limits have been raised on this context's device
     int row_line_taps = 16;   // streamed path: the row passes run on the one-wave-per-line kernels up to this many taps (WAVENET_HIP_ROW_LINE_TAPS)
     bool fused_hist = true;   // streamed path, 2D on lines: the column kernel builds the ranking's histograms (WAVENET_HIP_FUSED_HIST=0: kr_hist)
+    int rank_regions_from = 19;   // streamed path, errors wanted: from 2^this coefficients per example the ranks go home region by region (WAVENET_HIP_RANK_REGIONS_FROM)
+    int rank_regions_ib = 14;     // log2 of the positions per region then (WAVENET_HIP_RANK_REGIONS_IB, 13 .. 15)
+    bool regions_configured = false;
     bool rank_packed = true;  // streamed path: 8-byte packed staging keys (WAVENET_HIP_RANK_KEYS=12: magnitudes and indices side by side)
     int rank_sub = 0;         // streamed path: examples per partition + bucket-sort launch pair (WAVENET_HIP_RANK_SUB; 0: the whole chunk)
     int chunk_cap = 0;        // streamed path: examples per chunk at most (WAVENET_HIP_CHUNK; 0: as many as the workspace limit allows)

@@ -1066,7 +1066,9 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
     unsigned* hist = idxB;                                                           // B * NF words
     unsigned short* btab = reinterpret_cast<unsigned short*>(idxB + (size_t)B * NF);  // B * NF half words
     unsigned* rank = reinterpret_cast<unsigned*>(keysB);                              // B * n words
-    unsigned* meta = rank + (size_t)B * n;                                            // B * meta_words(n) words
+    // B * meta_words(n) words behind the bucket table (a multiple of 8 bytes in: NF is a multiple of 1024); the array of
+    // ranks then has its second half free for the (home index, rank) pairs of kr_delta_regions
+    unsigned* meta = reinterpret_cast<unsigned*>(btab + (size_t)B * NF);
     unsigned* flag = kmax + B + 4;   // beside the B words of kmax (the plan leaves 16 spare): nothing later in the chunk writes there
     unsigned long long* mag = reinterpret_cast<unsigned long long*>(keysA);
     // per context, i.e. per device: a function's attributes belong to the device it is loaded on
@@ -1097,6 +1099,11 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
     hipLaunchKernelGGL(kr_scan, dim3(B), dim3(RK_BT), (size_t)NF * 4, st, hist, kmax, NF, lgBPO, n, btab, meta, flag);
     const int sub = ctx->rank_sub > 0 ? std::min(ctx->rank_sub, B) : B;
     const bool packed = ctx->rank_packed;
+    // errors wanted and an example's ranks beyond what an L2 merges into whole lines: pairs in slot order, taken home
+    // region by region (one launch over the whole chunk, so not with sub-chunks)
+    bool by_regions = D && packed && sub == B && lgn >= ctx->rank_regions_from;
+    unsigned long long* pairs = reinterpret_cast<unsigned long long*>(keysB);
+    int ib_all = 0;
     const int steps_max = (int)(n >> RK_IB_MIN), nbe = nbmax_even(n);    // regions per example at most: what the snapshots are sized for
     // packed staging: cursor snapshots and (several workgroups per example) kr_count's counts in place of the index array
     unsigned short* snap = reinterpret_cast<unsigned short*>(idxA);
@@ -1105,8 +1112,11 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
         const int Bs = std::min(sub, B - s0);
         int Gs = 1;
         while ((long long)Gs * Bs < 2LL * ctx->numCU && n / (2 * (size_t)Gs) >= (size_t)std::max(RK_TILE, 1 << RK_IB_MIN)) Gs *= 2;   // (whole regions per workgroup)
-        const int ib = rank_ib(lgn, n / (size_t)Gs);
+        int ib = rank_ib(lgn, n / (size_t)Gs);
+        if (by_regions) ib = std::min(ib, ctx->rank_regions_ib);    // regions of 64 KB of ranks: two workgroups of kr_delta_regions per CU
         const int steps = (int)(n >> ib);
+        ib_all = ib;
+        if (((size_t)4 << ib) > (size_t)128 * 1024) by_regions = false;     // a region's ranks have to fit the LDS
         const double* Ys = Y + (size_t)s0 * n;
         const unsigned short* bts = btab + (size_t)s0 * NF;
         unsigned* ms = meta + (size_t)s0 * meta_words(n);
@@ -1120,11 +1130,13 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
                 pc = precnt;
             }
             hipLaunchKernelGGL(kr_part8, dim3(Gs, Bs), dim3(RK_PT), (size_t)NF * 2, st, Ys, n, bts, ms, NF, lgBPO, mag, sn, pc, flag, ib);
-            hipLaunchKernelGGL((kr_bucket<RK_LGNSB, true>), dim3(bgrid), dim3(RK_KT), 0, st, mag, (const unsigned*)nullptr, sn, Ys, n, lgn, ms, rks, Bs, flag, NF, lgBPO, ib);
+            hipLaunchKernelGGL((kr_bucket<RK_LGNSB, true>), dim3(bgrid), dim3(RK_KT), 0, st, mag, (const unsigned*)nullptr, sn, Ys, n, lgn, ms, rks, Bs, flag, NF, lgBPO, ib,
+                               by_regions ? pairs : (unsigned long long*)nullptr);
         } else {
             if (Gs == 1) hipLaunchKernelGGL(kr_part<true>, dim3(1, Bs), dim3(RK_PT), (size_t)NF * 2, st, Ys, n, bts, ms, NF, lgBPO, mag, idxA, flag);
             else hipLaunchKernelGGL(kr_part<false>, dim3(Gs, Bs), dim3(RK_PT), (size_t)NF * 2, st, Ys, n, bts, ms, NF, lgBPO, mag, idxA, flag);
-            hipLaunchKernelGGL((kr_bucket<RK_LGNSB, false>), dim3(bgrid), dim3(RK_KT), 0, st, mag, idxA, (const unsigned short*)nullptr, Ys, n, lgn, ms, rks, Bs, flag, NF, lgBPO, 0);
+            hipLaunchKernelGGL((kr_bucket<RK_LGNSB, false>), dim3(bgrid), dim3(RK_KT), 0, st, mag, idxA, (const unsigned short*)nullptr, Ys, n, lgn, ms, rks, Bs, flag, NF, lgBPO, 0,
+                               (unsigned long long*)nullptr);
         }
     }
     hipLaunchKernelGGL(kr_finish, dim3(B), dim3(64), 0, st, meta, n, B, fg, S_e);
@@ -1142,7 +1154,15 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
         WN_HIP(ctx, hipStreamSynchronize(st));
         if (over) return WN_OK;
     }
-    if (D) {
+    if (D && by_regions) {
+        if (!ctx->regions_configured) {
+            WN_HIP(ctx, hipFuncSetAttribute((const void*)kr_delta_regions, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            ctx->regions_configured = true;
+        }
+        hipLaunchKernelGGL(kr_delta_regions, dim3((unsigned)(n >> ib_all), B), dim3(RK_KT), (size_t)4 << ib_all, st, Y, pairs, snap, meta, n,
+                           ib_all, fg, D, flag);
+        WN_HIP(ctx, hipGetLastError());
+    } else if (D) {
         hipLaunchKernelGGL(kb_delta_home, grid_for((int)std::min<size_t>(n, 1u << 30), B), dim3(BT), 0, st, Y, rank, D, fg, (unsigned)n);
         WN_HIP(ctx, hipGetLastError());
     }

@@ -628,9 +628,12 @@ __device__ __forceinline__ unsigned bucket_slot(int tid, int k) {
 
 // so[k]: sub-bin of the thread's k-th magnitude in the low half; its place inside the sub-bin comes in and its rank
 // inside the bucket goes out in the high half (both below RK_CAP).
+// The rank goes to the coefficient's home position in rk, or -- pr given -- into the slot's place of pr as the pair
+// (home index << 32) | rank: consecutive addresses instead of one line per rank (kr_delta_regions takes them home).
 template <int LGNSB, bool SLOTS, bool PACKED8>
 __device__ __forceinline__ void bucket_ranks(BucketLds<LGNSB>& L, unsigned long long (&key)[RK_KE], unsigned (&so)[RK_KE],
-                                              unsigned count, int PB, const BucketHomes<PACKED8>& home, unsigned* rk, unsigned rank0) {
+                                              unsigned count, int PB, const BucketHomes<PACKED8>& home, unsigned* rk, unsigned rank0,
+                                              unsigned long long* pr) {
     const int tid = threadIdx.x;
     const unsigned pmask = (1u << PB) - 1u;
     if constexpr (!SLOTS) {
@@ -663,7 +666,11 @@ __device__ __forceinline__ void bucket_ranks(BucketLds<LGNSB>& L, unsigned long 
                 if (on && sz[k] > (unsigned)RK_W) {
                     for (unsigned q = g0[k] + RK_W; q < g0[k] + sz[k]; q++) r += (L.keyB[q] < key[h + k]) ? 1u : 0u;
                 }
-                if (on) rk[(unsigned)key[h + k] & pmask] = rank0 + r;
+                if (on) {
+                    const unsigned hm = (unsigned)key[h + k] & pmask;
+                    if (pr) pr[bucket_slot<PACKED8>(tid, h + k)] = ((unsigned long long)hm << 32) | (unsigned long long)(rank0 + r);
+                    else rk[hm] = rank0 + r;
+                }
                 so[h + k] = (so[h + k] & 0xFFFFu) | (r << 16);
             }
         }
@@ -686,7 +693,11 @@ __device__ __forceinline__ void bucket_ranks(BucketLds<LGNSB>& L, unsigned long 
                         }
                     }
                 }
-                rk[home(j)] = rank0 + r;
+                {
+                    const unsigned hm = home(j);
+                    if (pr) pr[j] = ((unsigned long long)hm << 32) | (unsigned long long)(rank0 + r);
+                    else rk[hm] = rank0 + r;
+                }
                 so[k] = (so[k] & 0xFFFFu) | (r << 16);
             }
         }
@@ -701,10 +712,12 @@ __device__ __forceinline__ void bucket_ranks(BucketLds<LGNSB>& L, unsigned long 
 // workgroup L works on example (L / 8 / nbmax) * 8 + L % 8 -- all buckets of an example share one XCD, whose L2
 // then collects the example's scattered ranks into whole lines.
 // PACKED8: the staging holds kr_part8's keys (mag) and cursor snapshots (snap); wide buckets read their magnitudes from Y.
+// pairs (may be null): the ranks leave as (home index, rank) pairs in slot order instead of going home (bucket_ranks).
 template <int LGNSB, bool PACKED8>
 __global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned long long* __restrict__ mag, const unsigned* __restrict__ idx,
                                                                  const unsigned short* __restrict__ snap, const double* __restrict__ Y, size_t n, int lgn,
-                                                                 unsigned* meta_all, unsigned* rank, int B, const unsigned* flag, int NF, int lgBPO, int ib) {
+                                                                 unsigned* meta_all, unsigned* rank, int B, const unsigned* flag, int NF, int lgBPO, int ib,
+                                                                 unsigned long long* pairs) {
     constexpr int NSB = 1 << LGNSB;
     constexpr int SPT = NSB / RK_KT;            // sub-bins per thread in the prefix sum
     static_assert(SPT % 4 == 0 && RK_CAP == RK_KE * RK_KT, "whole 16-byte pieces of counters per thread; RK_KE magnitudes per thread");
@@ -856,8 +869,9 @@ __global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned l
     unsigned* rk = rank + (size_t)e * n;
     const unsigned rank0 = zeros + s0 + 1u;
     const BucketHomes<PACKED8> home{ii, mi, L.col, steps, ib};
-    if (!slots) bucket_ranks<LGNSB, false, PACKED8>(L, key, so, count, PB, home, rk, rank0);
-    else bucket_ranks<LGNSB, true, PACKED8>(L, key, so, count, PB, home, rk, rank0);
+    unsigned long long* pr = pairs ? pairs + (size_t)e * n + s0 : nullptr;       // (an array of its own: the staging is still read for ties)
+    if (!slots) bucket_ranks<LGNSB, false, PACKED8>(L, key, so, count, PB, home, rk, rank0, pr);
+    else bucket_ranks<LGNSB, true, PACKED8>(L, key, so, count, PB, home, rk, rank0, pr);
     double f = 0, a = 0;
     const double w0 = 2.0 * (double)rank0 - (double)n - 1.0;     // weight of the bucket's smallest magnitude (exact: integers below 2^53)
     if constexpr (PACKED8 && RK_SUMS_IN_PLACE) {
@@ -899,6 +913,81 @@ __global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned l
 #pragma unroll
         for (int w = 0; w < RK_KT / 64; w++) t += L.red[tid * (RK_KT / 64) + w];
         meta_bpart(meta, nbmax)[2 * b + tid] = t;
+    }
+}
+
+// Errors on the coefficients from kr_bucket's (home index, rank) pairs, region by region: for examples whose ranks do
+// not fit an L2 (2^20 coefficients: 4 MB), ranks stored home one by one leave the cache as partially written lines
+// over and over (measured: 381 MB written for 32 MB of ranks).  A bucket's slots are ordered by region (kr_part8
+// appends region after region, and its cursor snapshots say where each region's slots begin), so the workgroup of
+// region r reads, bucket by bucket, the run of pairs that belongs to it -- consecutive addresses -- drops the ranks
+// at (home index mod region) in LDS, and then streams over its 2^ib coefficients:
+//   delta_j = -((2 rank_j - n - 1) sign g - f n sign) / g^2   (kb_delta_home's expression; Dout may be Yin).
+// Exact zeros have no pair and need none.  grid (n >> ib, B), RK_KT threads, (4 << ib) bytes of dynamic LDS.
+__global__ __launch_bounds__(RK_KT) void kr_delta_regions(const double* Yin, const unsigned long long* __restrict__ pairs,
+                                                          const unsigned short* __restrict__ snap, const unsigned* __restrict__ meta_all,
+                                                          size_t n, int ib, const double* __restrict__ fg, double* Dout, const unsigned* flag) {
+    extern __shared__ unsigned rk_home[];
+    __shared__ unsigned run0[RK_NBMAX];              // per bucket: where the region's run of pairs starts, and its length
+    __shared__ unsigned short runn[RK_NBMAX];
+    if (*flag) return;
+    const int r = blockIdx.x, e = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int steps = (int)(n >> ib), nbe = nbmax_even(n);
+    const unsigned* meta = meta_all + (size_t)e * meta_words(n);
+    const int nb = min((int)meta[1], RK_NBMAX);
+    const unsigned short* s0 = snap + ((size_t)e * steps + r) * nbe;
+    const unsigned mask = (1u << ib) - 1u;
+    const unsigned long long* pe = pairs + (size_t)e * n;
+    for (int b = tid; b < nb; b += RK_KT) {          // all buckets' runs at once: their descriptors come from memory
+        const unsigned bs = meta_bstart(meta)[b], count = meta_bstart(meta)[b + 1] - bs;
+        unsigned lo = 0, hi = 0;
+        if (count <= (unsigned)RK_CAP) {             // (an overfull bucket has raised the flag)
+            lo = min((unsigned)s0[b], count);
+            hi = (r + 1 < steps) ? min((unsigned)s0[nbe + b], count) : count;
+            hi = max(hi, lo);
+        }
+        run0[b] = bs + lo;
+        runn[b] = (unsigned short)(hi - lo);
+    }
+    __syncthreads();
+    // a wave takes four buckets at a time, two blocks of 64 pairs of each: eight loads in flight
+    constexpr int NW = RK_KT / 64;
+    for (int b0 = wave; b0 < nb; b0 += 4 * NW) {
+        unsigned long long v[4][2];
+        unsigned len[4], base[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int b = b0 + q * NW;
+            len[q] = (b < nb) ? (unsigned)runn[b] : 0u;
+            base[q] = (b < nb) ? run0[b] : 0u;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const unsigned j = (unsigned)lane + 64u * (unsigned)h;
+                v[q][h] = pe[base[q] + (j < len[q] ? j : 0u)];            // (the address stays inside the example either way)
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if ((unsigned)lane + 64u * (unsigned)h < len[q]) rk_home[(unsigned)(v[q][h] >> 32) & mask] = (unsigned)v[q][h];
+            }
+            for (unsigned j = 128u + (unsigned)lane; j < len[q]; j += 64u) {     // runs beyond 128 pairs
+                const unsigned long long w = pe[base[q] + j];
+                rk_home[(unsigned)(w >> 32) & mask] = (unsigned)w;
+            }
+        }
+    }
+    __syncthreads();
+    const size_t off = (size_t)e * n + ((size_t)r << ib);
+    const double f = fg[2 * e], g = fg[2 * e + 1], dn = (double)n;
+    const double inv_g2 = 1.0 / (g * g);
+    for (unsigned j = (unsigned)tid; j <= mask; j += RK_KT) {
+        const double y = Yin[off + j];
+        const double sg = sign_ref(y);
+        const double coef = (y != 0.0) ? 2.0 * (double)rk_home[j] - dn - 1.0 : 0.0;
+        const double df = coef * sg;
+        Dout[off + j] = -(df * g - f * (dn * sg)) * inv_g2;
     }
 }
 
