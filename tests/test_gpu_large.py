@@ -429,7 +429,8 @@ def test_histograms_built_by_the_column_kernel(oracle, R, C, N, B):
     """With an example per CU or more and both passes on the line kernels, the column kernel leaves the ranking's
     histograms and largest magnitudes itself (kc_fwd_cols_hist) instead of kr_hist reading the coefficients
     back.  The histograms are the same numbers, so every sum and per-example value is bit for bit the one of the
-    path with WAVENET_HIP_FUSED_HIST=0; two examples are checked against the oracle.  Examples scaled by 1e-30 and
+    path with WAVENET_HIP_FUSED_HIST=0, and of the path that stores ranks at home positions (WAVENET_HIP_RANK_PAIRS=0)
+    instead of handing (home index, rank) pairs to the column backward kernel; three examples are checked against the oracle.  Examples scaled by 1e-30 and
     1e30 sit far from the others' magnitudes; in the second batch the taps are scaled by 1e4, which puts the
     kernel's bound on the largest magnitude so far above the truth that it hands every example to kr_hist; a NaN
     in one example goes the same way, and an image of zeros has nothing to count."""
@@ -441,16 +442,22 @@ def test_histograms_built_by_the_column_kernel(oracle, R, C, N, B):
     X[2] *= 1e30
     fused = _ctx_with_env("WAVENET_HIP_FUSED_HIST", "1")
     plain = _ctx_with_env("WAVENET_HIP_FUSED_HIST", "0")
+    home = _ctx_with_env("WAVENET_HIP_RANK_PAIRS", "0")     # ranks stored at home positions instead of (home, rank) pairs per region
     try:
         dX = to_dev(X)
         out = {}
-        for name, c in (("fused", fused), ("plain", plain)):
+        for name, c in (("fused", fused), ("plain", plain), ("home", home)):
             c.set_filter(a)
             dG, dS = dev_empty(B * N), dev_empty(B)
             c.train_batch(dX, B, R, C, dG, dS)
             out[name] = (c.sums().copy(), dG.cpu().numpy().reshape(B, N), dS.cpu().numpy())
         for k in range(3):
             assert np.array_equal(out["fused"][k], out["plain"][k]), k
+        # the region-wise kernel adds a wave's window sums over other columns than the home-rank kernel: same ranks, same
+        # errors, filter gradients equal to rounding; the sparsity terms come from the ranking alone and are the same bits
+        assert np.array_equal(out["fused"][2], out["home"][2])
+        assert relerr(out["fused"][1], out["home"][1]) < 1e-12
+        assert relerr(out["fused"][0][:N + 1], out["home"][0][:N + 1]) < 1e-12
         assert out["fused"][0][N + 1] == 0
         for e in (0, 1, 2):
             ge, se, _ = oracle.band_train_batch(a, X[e:e + 1])
@@ -472,6 +479,7 @@ def test_histograms_built_by_the_column_kernel(oracle, R, C, N, B):
         torch.cuda.synchronize()
         fused.close()
         plain.close()
+        home.close()
 
 
 def test_full_batch_of_512x512_against_its_parts(ctx):

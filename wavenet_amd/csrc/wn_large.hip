@@ -31,7 +31,7 @@ namespace wn {
 namespace {
 
 // One-wave-per-line kernels (wn_lines.h, compiled per tap count in wn_lines_np.hip, up to 16 taps).
-enum { LN_FWD_COLS = 0, LN_BWD_COLS = 1, LN_BWD_COLS_RANKS = 2, LN_FWD_ROWS = 3, LN_GRAD_ROWS = 4, LN_FWD_COLS_HIST = 5 };
+enum { LN_FWD_COLS = 0, LN_BWD_COLS = 1, LN_BWD_COLS_RANKS = 2, LN_FWD_ROWS = 3, LN_GRAD_ROWS = 4, LN_FWD_COLS_HIST = 5, LN_BWD_COLS_REGIONS = 6 };
 constexpr int LN_HIST_T = 1024, LN_HIST_BINS = 36864;   // kc_fwd_cols_hist (wn_lines.h)
 const void* line_kernel(int np, int kind, int M) {
     switch (np) {
@@ -1049,11 +1049,22 @@ void rank_bins(size_t n, int* NF, int* lgBPO) {
 // *ok = false: some bucket would overflow (or the example is too long) -- nothing usable was written.
 // kmax: B words, and 16 spare ones of which one serves as the give-up flag; kmax_ready: the producer of Y has raised
 // them already (and its caller zeroed all B + 16 words before that).
+// What a consumer of (home index, rank) pairs needs to find them (kc_bwd_cols_regions, wn_lines.h).  want: the caller can
+// take pairs; used: pairs it is (32-bit ones in keysB, example e at word e * n; no ranks at home positions were written).
+struct RankPairs {
+    bool want = false, used = false;
+    const unsigned* pairs = nullptr;
+    const unsigned short* snap = nullptr;
+    const unsigned* meta = nullptr;
+    const unsigned* flag = nullptr;
+    int meta_stride = 0, nbe = 0, ib = 0;
+};
+
 // hist_need (with kmax_ready): the producer has also left the histograms (in idxB, where kr_hist puts them) of all
 // examples but those it marked in hist_need[e].
 int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB, unsigned* idxA,
                  unsigned* idxB, double* fg, double* S_e, unsigned* kmax, bool kmax_ready, bool* ok, const unsigned** pending = nullptr,
-                 const unsigned* hist_need = nullptr) {
+                 const unsigned* hist_need = nullptr, RankPairs* rp = nullptr) {
     using namespace rk;
     *ok = false;
     int lgn = 0;
@@ -1104,6 +1115,9 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
     bool by_regions = D && packed && sub == B && lgn >= ctx->rank_regions_from;
     unsigned long long* pairs = reinterpret_cast<unsigned long long*>(keysB);
     int ib_all = 0;
+    // no array of errors wanted, and the consumer of the ranks takes pairs: the same, with regions small enough for its LDS
+    // (32-bit pairs: the rank, up to n, beside RK_IB_MIN bits of home index)
+    const bool pairs_out = !D && rp && rp->want && packed && sub == B && lgn + 1 + RK_IB_MIN <= 32;
     const int steps_max = (int)(n >> RK_IB_MIN), nbe = nbmax_even(n);    // regions per example at most: what the snapshots are sized for
     // packed staging: cursor snapshots and (several workgroups per example) kr_count's counts in place of the index array
     unsigned short* snap = reinterpret_cast<unsigned short*>(idxA);
@@ -1114,6 +1128,7 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
         while ((long long)Gs * Bs < 2LL * ctx->numCU && n / (2 * (size_t)Gs) >= (size_t)std::max(RK_TILE, 1 << RK_IB_MIN)) Gs *= 2;   // (whole regions per workgroup)
         int ib = rank_ib(lgn, n / (size_t)Gs);
         if (by_regions) ib = std::min(ib, ctx->rank_regions_ib);    // regions of 64 KB of ranks: two workgroups of kr_delta_regions per CU
+        if (pairs_out) ib = RK_IB_MIN;                              // regions of 32 KB of ranks
         const int steps = (int)(n >> ib);
         ib_all = ib;
         if (((size_t)4 << ib) > (size_t)128 * 1024) by_regions = false;     // a region's ranks have to fit the LDS
@@ -1131,16 +1146,26 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
             }
             hipLaunchKernelGGL(kr_part8, dim3(Gs, Bs), dim3(RK_PT), (size_t)NF * 2, st, Ys, n, bts, ms, NF, lgBPO, mag, sn, pc, flag, ib);
             hipLaunchKernelGGL((kr_bucket<RK_LGNSB, true>), dim3(bgrid), dim3(RK_KT), 0, st, mag, (const unsigned*)nullptr, sn, Ys, n, lgn, ms, rks, Bs, flag, NF, lgBPO, ib,
-                               by_regions ? pairs : (unsigned long long*)nullptr);
+                               (by_regions || pairs_out) ? pairs : (unsigned long long*)nullptr, pairs_out ? ib : 0);
         } else {
             if (Gs == 1) hipLaunchKernelGGL(kr_part<true>, dim3(1, Bs), dim3(RK_PT), (size_t)NF * 2, st, Ys, n, bts, ms, NF, lgBPO, mag, idxA, flag);
             else hipLaunchKernelGGL(kr_part<false>, dim3(Gs, Bs), dim3(RK_PT), (size_t)NF * 2, st, Ys, n, bts, ms, NF, lgBPO, mag, idxA, flag);
             hipLaunchKernelGGL((kr_bucket<RK_LGNSB, false>), dim3(bgrid), dim3(RK_KT), 0, st, mag, idxA, (const unsigned short*)nullptr, Ys, n, lgn, ms, rks, Bs, flag, NF, lgBPO, 0,
-                               (unsigned long long*)nullptr);
+                               (unsigned long long*)nullptr, 0);
         }
     }
     hipLaunchKernelGGL(kr_finish, dim3(B), dim3(64), 0, st, meta, n, B, fg, S_e);
     WN_HIP(ctx, hipGetLastError());
+    if (pairs_out) {
+        rp->used = true;
+        rp->pairs = reinterpret_cast<const unsigned*>(pairs);
+        rp->snap = snap;
+        rp->meta = meta;
+        rp->flag = flag;
+        rp->meta_stride = (int)meta_words(n);
+        rp->nbe = nbe;
+        rp->ib = ib_all;
+    }
     if (pending) {
         // the caller looks at the flag when it has queued everything that follows, and starts over if it is up; what the
         // kernels in between compute from unfinished ranks is arithmetic on garbage, never an address.  The event marks
@@ -1175,7 +1200,7 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
 int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB,
                unsigned* idxA, unsigned* idxB, unsigned* cnt, double* gpart, double* fg, double* S_e, void* sort_tmp,
                size_t sort_tmp_bytes, int* rank_slice = nullptr, bool counts_ready = false, unsigned* kmax = nullptr,
-               bool kmax_ready = false, const unsigned** pending = nullptr, const unsigned* hist_need = nullptr) {
+               bool kmax_ready = false, const unsigned** pending = nullptr, const unsigned* hist_need = nullptr, RankPairs* rp = nullptr) {
     // rank_slice (with D null): receives the number of examples per slice when the ranks were left in keysB
     // (slice s at keysB + s * slice * n, as 32-bit ranks at home positions) for a consumer that computes
     // the errors itself, 0 when this path did not apply and only the sums were computed.
@@ -1185,7 +1210,8 @@ int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, dou
     while (((size_t)1 << lgn) < n) lgn++;
     if (ctx->bucket_rank && !ctx->exact_sort && kmax) {
         bool ok = false;
-        const int rc = gini_buckets(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, fg, S_e, kmax, kmax_ready, &ok, pending, hist_need);
+        const int rc = gini_buckets(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, fg, S_e, kmax, kmax_ready, &ok, pending, hist_need, rp);
+        if (!ok && rp) rp->used = false;
         if (rc) return rc;
         if (ok) {
             if (rank_slice) *rank_slice = B;   // one slice: example e's ranks at (unsigned*)keysB + e * n
@@ -1403,8 +1429,11 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         // with the column kernels the errors on the coefficients are computed inside the backward kernel from
         // the ranks; otherwise (or when the short-key ranking did not apply) they replace the coefficients in YD
         int rank_slice = 0;
+        RankPairs rp;
+        // (up to 8 taps: at 16 the kernels run one wave per SIMD, where nothing hides the gather of a region's pairs: measured 25.7 against 24.3 ms)
+        rp.want = colLines && buckets && ctx->rank_pairs_cols && NP <= 8 && ((size_t)1 << rk::RK_IB_MIN) % (size_t)R == 0 && n >= ((size_t)1 << rk::RK_IB_MIN);
         if (colLines && (rc = gini_large(ctx, YD, nullptr, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp,
-                                         pl.sort_tmp_bytes, &rank_slice, !buckets, buckets ? pl.kmax : nullptr, buckets, pending, histNeed)))
+                                         pl.sort_tmp_bytes, &rank_slice, !buckets, buckets ? pl.kmax : nullptr, buckets, pending, histNeed, &rp)))
             return rc;
         if (!rank_slice &&
             (rc = gini_large(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes,
@@ -1414,7 +1443,18 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         const int pgx = (rowLines || colLines) ? GXMAX : pl.pgx;
         WN_HIP(ctx, hipMemsetAsync(pl.partial, 0, (size_t)Bc * pgx * 2 * NP * sizeof(double), st));
         const double* D1 = nullptr;
-        if (colLines) {
+        if (colLines && rank_slice && rp.used) {
+            const double* y1c = Y1;
+            double* out = pl.A;
+            const double* fgp = pl.fg;
+            const void* fn = line_kernel(NP, LN_BWD_COLS_REGIONS, Mcol);
+            const size_t lds = ((size_t)4 << rp.ib) + (size_t)6 * rp.nbe + 16;
+            void* args[] = {(void*)&y1c, (void*)&out, (void*)&xs, (void*)&ncols, (void*)&dfilt, (void*)&partial, (void*)&rp.pairs,
+                            (void*)&rp.snap, (void*)&rp.meta, (void*)&rp.meta_stride, (void*)&rp.nbe, (void*)&rp.ib, (void*)&fgp, (void*)&rp.flag};
+            const int regions = (int)(n >> rp.ib);
+            WN_HIP(ctx, hipLaunchKernel(fn, dim3(std::min(regions, LN_GX / 4), Bc), dim3(256), args, lds, st));
+            D1 = pl.A;
+        } else if (colLines) {
             const double* y1c = Y1;
             double* out = pl.A;
             const double* ranks = rank_slice ? pl.Bb : nullptr;

@@ -403,6 +403,123 @@ __global__ __launch_bounds__(256, (NP >= LN_ONE_WAVE_FROM ? 1 : LN_BWD_COLS_WAVE
     }
 }
 
+// kc_bwd_cols from the bucket ranking's (home index, rank) pairs instead of ranks at home positions.  The ranking then
+// writes consecutive addresses (one 32-bit pair per slot of a bucket: home index mod region in the upper ib bits, the
+// rank below, which takes examples of up to 2^(31 - ib) coefficients) instead of one cache line per rank, which is
+// what bounds its last kernel: 537 M four-byte stores per step of 2048 images of 512x512 are 2 ms of L2 requests.
+// A bucket's slots are ordered by region of 2^ib home positions (a whole number of columns), and the partition's
+// cursor snapshots say where a region's run begins in every bucket: a workgroup gathers the runs of its region
+// into LDS -- descriptors first, then sixteen loads in flight per wave -- which puts the region's ranks at
+// (home index mod region), and then works through the region's columns as kc_bwd_cols does, four waves on columns
+// of their own, the ranks read from LDS.  Layout of the ranking's tables (wn_rank.h): per example meta_stride words,
+// word 1 = number of buckets, words 4 .. = bucket starts; snap[(example * regions + region) * nbe + bucket] = 16-bit
+// offset of the region's first slot in the bucket; a bucket of more than LN_BUCKET_CAP slots has raised the flag.
+// grid (workgroups per example: 4 * grid.x <= LN_GX, examples), 256 threads, dynamic LDS (4 << ib) + 6 * nbe bytes.
+constexpr unsigned LN_BUCKET_CAP = 4096;
+#ifndef LN_RUNS
+#define LN_RUNS 8        // runs a wave fetches at a time: 16 loads in flight
+#endif
+template <int NP, int M>
+__global__ __launch_bounds__(256, (NP >= LN_ONE_WAVE_FROM ? 1 : LN_BWD_COLS_WAVES)) void kc_bwd_cols_regions(
+    const double* __restrict__ in, double* __restrict__ out, size_t xs, int ncols, const FilterDev* filt, double* partial,
+    const unsigned* __restrict__ pairs, const unsigned short* __restrict__ snap, const unsigned* __restrict__ meta_all,
+    int meta_stride, int nbe, int ib, const double* fg, const unsigned* flag) {
+    extern __shared__ unsigned ln_rk[];
+    const int lane0 = threadIdx.x & 63, wave0 = threadIdx.x >> 6;
+    const int slot = blockIdx.x * 4 + wave0;
+    double a[NP], b[NP];
+    ln_load_taps<NP>(filt, a, b);
+    double gL[NP], gH[NP];
+#pragma unroll
+    for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
+    const int e = blockIdx.y;
+    const size_t off = (size_t)e * xs;
+    LineGini gini{fg[2 * e], fg[2 * e + 1], 0, (double)xs};
+    gini.inv_g2 = 1.0 / (gini.g * gini.g);
+    const int regions = (int)(xs >> ib), cpr = (1 << ib) / (64 * M);      // columns per region
+    const unsigned* meta = meta_all + (size_t)e * meta_stride;
+    const unsigned* bstart = meta + 4;
+    const int nb = (*flag) ? 0 : min((int)meta[1], nbe);
+    unsigned* run0 = ln_rk + (1u << ib);
+    unsigned short* runn = reinterpret_cast<unsigned short*>(run0 + nbe);
+    const int rb = 32 - ib;                               // a pair: (home index mod region) << rb | rank
+    const unsigned rmask = (1u << rb) - 1u;
+    const unsigned* pe = pairs + off;
+    for (int r = blockIdx.x; r < regions; r += gridDim.x) {
+        const int tid = ln_opaque((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
+        __syncthreads();                                   // the ranks of the region before are done with
+        const unsigned short* s0 = snap + ((size_t)e * regions + r) * nbe;
+        for (int bk = tid; bk < nb; bk += 256) {
+            const unsigned bs = bstart[bk], count = bstart[bk + 1] - bs;
+            unsigned lo = 0, hi = 0;
+            if (count <= LN_BUCKET_CAP) {
+                lo = min((unsigned)s0[bk], count);
+                hi = (r + 1 < regions) ? min((unsigned)s0[nbe + bk], count) : count;
+                hi = max(hi, lo);
+            }
+            run0[bk] = bs + lo;
+            runn[bk] = (unsigned short)(hi - lo);
+        }
+        __syncthreads();
+        for (int b0 = wave; b0 < nb; b0 += 4 * LN_RUNS) {
+            unsigned v[LN_RUNS][2];
+            unsigned len[LN_RUNS], base[LN_RUNS];
+#pragma unroll
+            for (int q = 0; q < LN_RUNS; q++) {
+                const int bk = b0 + 4 * q;
+                len[q] = (bk < nb) ? (unsigned)runn[bk] : 0u;
+                base[q] = (bk < nb) ? run0[bk] : 0u;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const unsigned j = (unsigned)lane + 64u * (unsigned)h;
+                    v[q][h] = pe[base[q] + (j < len[q] ? j : 0u)];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < LN_RUNS; q++) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if ((unsigned)lane + 64u * (unsigned)h < len[q]) ln_rk[v[q][h] >> rb] = v[q][h] & rmask;
+                }
+                for (unsigned j = 128u + (unsigned)lane; j < len[q]; j += 64u) {
+                    const unsigned w = pe[base[q] + j];
+                    ln_rk[w >> rb] = w & rmask;
+                }
+            }
+        }
+        __syncthreads();
+        for (int cl = wave; cl < cpr; cl += 4) {
+            const int c = r * cpr + cl;
+            if (c >= ncols) break;
+            const size_t lo = off + (size_t)c * (64 * M);
+            LinePyramid<M> p;
+            LineLane<M> dy;
+            double unused_lo;
+            ln_load_samples<M>(in + lo, p.x, lane);
+            ln_forward<NP, M>(p, a, b, lane, dy, unused_lo);       // the coefficients, recomputed (kc_bwd_cols)
+            const unsigned* rc = ln_rk + cl * (64 * M);
+            dy.v[0] = gini.delta(dy.v[0], rc[lane]);
+            dy.v[1] = gini.delta(dy.v[1], rc[64 + lane]);
+            ln_delta_levels<M, 2>(dy, gini, rc, lane);
+            double dtop[M];
+            if (out) {
+                ln_backward<NP, M, true>(p, dy, dtop, a, b, gL, gH, lane);
+                ln_store_samples<M>(out + lo, dtop, lane);
+            } else {
+                ln_backward<NP, M, false>(p, dy, dtop, a, b, gL, gH, lane);
+            }
+        }
+    }
+    double* part = partial + ((size_t)blockIdx.y * LN_GX + slot) * 2 * NP;
+#pragma unroll
+    for (int u = 0; u < NP; u++) {
+        double sl = gL[u], sh = gH[u];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sl += __shfl_xor(sl, o, 64); sh += __shfl_xor(sh, o, 64); }
+        if (lane0 == 0) { part[u] += sl; part[NP + u] += sh; }
+    }
+}
+
 // ---- rows: lines of 64 M samples strided by the number of rows -------------------------------------------
 // Tile: ROWS rows x 64 M columns in LDS, row stride RS doubles, element c of a row at c + c / M: a lane's M
 // samples sit M + 1 doubles from its neighbour's (conflict-free 8-byte reads), and the row pairs x columns

@@ -1,7 +1,7 @@
 // Instantiates the one-wave-per-line kernels of the streamed path (wn_lines.h) for one compiled tap count
 // (-DWN_NP=2|4|8|16|32) and exports their addresses.  kind 0: columns forward, 1: columns backward from
 // errors, 2: columns backward from ranks, 3: rows forward, 4: rows filter gradient, 5: columns forward with the
-// ranking's histogram; M = samples per lane
+// ranking's histogram, 6: columns backward from (home index, rank) pairs; M = samples per lane
 // (line length / 64): 2, 4, 8 or 16.
 #include "wn_lines.h"
 
@@ -22,6 +22,7 @@ const void* pick(int kind) {
         case 3: return (const void*)&wn::kr_fwd_rows<WN_NP, M>;
         case 4: return (const void*)&wn::kr_grad_rows<WN_NP, M>;
         case 5: return (const void*)&wn::kc_fwd_cols_hist<WN_NP, M>;
+        case 6: return (const void*)&wn::kc_bwd_cols_regions<WN_NP, M>;
     }
     return nullptr;
 }

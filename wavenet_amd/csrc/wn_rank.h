@@ -630,10 +630,12 @@ __device__ __forceinline__ unsigned bucket_slot(int tid, int k) {
 // inside the bucket goes out in the high half (both below RK_CAP).
 // The rank goes to the coefficient's home position in rk, or -- pr given -- into the slot's place of pr as the pair
 // (home index << 32) | rank: consecutive addresses instead of one line per rank (kr_delta_regions takes them home).
+// pr32 > 0: pr is an array of 32-bit words and the pair is (home index mod 2^pr32) << (32 - pr32) | rank -- the
+// consumer knows the region from where it reads (kc_bwd_cols_regions); the rank must fit 32 - pr32 bits.
 template <int LGNSB, bool SLOTS, bool PACKED8>
 __device__ __forceinline__ void bucket_ranks(BucketLds<LGNSB>& L, unsigned long long (&key)[RK_KE], unsigned (&so)[RK_KE],
                                               unsigned count, int PB, const BucketHomes<PACKED8>& home, unsigned* rk, unsigned rank0,
-                                              unsigned long long* pr) {
+                                              unsigned long long* pr, int pr32) {
     const int tid = threadIdx.x;
     const unsigned pmask = (1u << PB) - 1u;
     if constexpr (!SLOTS) {
@@ -668,7 +670,8 @@ __device__ __forceinline__ void bucket_ranks(BucketLds<LGNSB>& L, unsigned long 
                 }
                 if (on) {
                     const unsigned hm = (unsigned)key[h + k] & pmask;
-                    if (pr) pr[bucket_slot<PACKED8>(tid, h + k)] = ((unsigned long long)hm << 32) | (unsigned long long)(rank0 + r);
+                    if (pr32) reinterpret_cast<unsigned*>(pr)[bucket_slot<PACKED8>(tid, h + k)] = ((hm & ((1u << pr32) - 1u)) << (32 - pr32)) | (rank0 + r);
+                    else if (pr) pr[bucket_slot<PACKED8>(tid, h + k)] = ((unsigned long long)hm << 32) | (unsigned long long)(rank0 + r);
                     else rk[hm] = rank0 + r;
                 }
                 so[h + k] = (so[h + k] & 0xFFFFu) | (r << 16);
@@ -695,7 +698,8 @@ __device__ __forceinline__ void bucket_ranks(BucketLds<LGNSB>& L, unsigned long 
                 }
                 {
                     const unsigned hm = home(j);
-                    if (pr) pr[j] = ((unsigned long long)hm << 32) | (unsigned long long)(rank0 + r);
+                    if (pr32) reinterpret_cast<unsigned*>(pr)[j] = ((hm & ((1u << pr32) - 1u)) << (32 - pr32)) | (rank0 + r);
+                    else if (pr) pr[j] = ((unsigned long long)hm << 32) | (unsigned long long)(rank0 + r);
                     else rk[hm] = rank0 + r;
                 }
                 so[k] = (so[k] & 0xFFFFu) | (r << 16);
@@ -717,7 +721,7 @@ template <int LGNSB, bool PACKED8>
 __global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned long long* __restrict__ mag, const unsigned* __restrict__ idx,
                                                                  const unsigned short* __restrict__ snap, const double* __restrict__ Y, size_t n, int lgn,
                                                                  unsigned* meta_all, unsigned* rank, int B, const unsigned* flag, int NF, int lgBPO, int ib,
-                                                                 unsigned long long* pairs) {
+                                                                 unsigned long long* pairs, int pairs32) {
     constexpr int NSB = 1 << LGNSB;
     constexpr int SPT = NSB / RK_KT;            // sub-bins per thread in the prefix sum
     static_assert(SPT % 4 == 0 && RK_CAP == RK_KE * RK_KT, "whole 16-byte pieces of counters per thread; RK_KE magnitudes per thread");
@@ -869,9 +873,12 @@ __global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned l
     unsigned* rk = rank + (size_t)e * n;
     const unsigned rank0 = zeros + s0 + 1u;
     const BucketHomes<PACKED8> home{ii, mi, L.col, steps, ib};
-    unsigned long long* pr = pairs ? pairs + (size_t)e * n + s0 : nullptr;       // (an array of its own: the staging is still read for ties)
-    if (!slots) bucket_ranks<LGNSB, false, PACKED8>(L, key, so, count, PB, home, rk, rank0, pr);
-    else bucket_ranks<LGNSB, true, PACKED8>(L, key, so, count, PB, home, rk, rank0, pr);
+    // (an array of its own: the staging is still read for ties; with 32-bit pairs, example e at word e * n)
+    unsigned long long* pr = !pairs ? nullptr
+                             : pairs32 ? reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned*>(pairs) + (size_t)e * n + s0)
+                                       : pairs + (size_t)e * n + s0;
+    if (!slots) bucket_ranks<LGNSB, false, PACKED8>(L, key, so, count, PB, home, rk, rank0, pr, pairs32);
+    else bucket_ranks<LGNSB, true, PACKED8>(L, key, so, count, PB, home, rk, rank0, pr, pairs32);
     double f = 0, a = 0;
     const double w0 = 2.0 * (double)rank0 - (double)n - 1.0;     // weight of the bucket's smallest magnitude (exact: integers below 2^53)
     if constexpr (PACKED8 && RK_SUMS_IN_PLACE) {
