@@ -317,6 +317,7 @@ int wn_create(int device, wn_context** out) {
     if (const char* w = getenv("WAVENET_HIP_ROW_LINE_TAPS")) ctx->row_line_taps = std::min(16, std::max(0, atoi(w)));
     if (const char* w = getenv("WAVENET_HIP_FUSED_HIST")) ctx->fused_hist = (strcmp(w, "0") != 0);
     if (const char* w = getenv("WAVENET_HIP_RANK_PAIRS")) ctx->rank_pairs_cols = (strcmp(w, "0") != 0);
+    if (const char* w = getenv("WAVENET_HIP_RANK_PAIRS_TAPS")) ctx->rank_pairs_taps = atoi(w);
     if (const char* w = getenv("WAVENET_HIP_RANK_REGIONS_FROM")) ctx->rank_regions_from = std::min(64, std::max(0, atoi(w)));
     if (const char* w = getenv("WAVENET_HIP_RANK_REGIONS_IB")) ctx->rank_regions_ib = std::min(15, std::max(13, atoi(w)));
     if (const char* w = getenv("WAVENET_HIP_RANK_KEYS")) ctx->rank_packed = (strcmp(w, "12") != 0);

@@ -33,6 +33,7 @@ struct wn_context {
     int row_line_taps = 16;   // streamed path: the row passes run on the one-wave-per-line kernels up to this many taps (WAVENET_HIP_ROW_LINE_TAPS)
     bool fused_hist = true;   // streamed path, 2D on lines: the column kernel builds the ranking's histograms (WAVENET_HIP_FUSED_HIST=0: kr_hist)
     bool rank_pairs_cols = true;  // streamed path, 2D on lines: the column backward kernel takes (home index, rank) pairs region by region (WAVENET_HIP_RANK_PAIRS=0: ranks at home positions)
+    int rank_pairs_taps = 8;      // ... up to this many taps (WAVENET_HIP_RANK_PAIRS_TAPS)
     int rank_regions_from = 19;   // streamed path, errors wanted: from 2^this coefficients per example the ranks go home region by region (WAVENET_HIP_RANK_REGIONS_FROM)
     int rank_regions_ib = 14;     // log2 of the positions per region then (WAVENET_HIP_RANK_REGIONS_IB, 13 .. 15)
     bool regions_configured = false;

@@ -1431,7 +1431,7 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         int rank_slice = 0;
         RankPairs rp;
         // (up to 8 taps: at 16 the kernels run one wave per SIMD, where nothing hides the gather of a region's pairs: measured 25.7 against 24.3 ms)
-        rp.want = colLines && buckets && ctx->rank_pairs_cols && NP <= 8 && ((size_t)1 << rk::RK_IB_MIN) % (size_t)R == 0 && n >= ((size_t)1 << rk::RK_IB_MIN);
+        rp.want = colLines && buckets && ctx->rank_pairs_cols && NP <= ctx->rank_pairs_taps && ((size_t)1 << rk::RK_IB_MIN) % (size_t)R == 0 && n >= ((size_t)1 << rk::RK_IB_MIN);
         if (colLines && (rc = gini_large(ctx, YD, nullptr, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp,
                                          pl.sort_tmp_bytes, &rank_slice, !buckets, buckets ? pl.kmax : nullptr, buckets, pending, histNeed, &rp)))
             return rc;
