@@ -346,8 +346,11 @@ __global__ __launch_bounds__(LN_HIST_T) void kc_fwd_cols_hist(const double* __re
 #ifndef LN_BWD_COLS_WAVES
 #define LN_BWD_COLS_WAVES 2
 #endif
+#ifndef LN_BWD_COLS_ONE_WAVE_FROM
+#define LN_BWD_COLS_ONE_WAVE_FROM 32      // (16 taps: 268 registers at one wave per SIMD; at two, 36 bytes of scratch and a quarter faster)
+#endif
 template <int NP, int M, bool FROM_RANKS>
-__global__ __launch_bounds__(256, (NP >= LN_ONE_WAVE_FROM ? 1 : LN_BWD_COLS_WAVES)) void kc_bwd_cols(const double* __restrict__ coef, const double* __restrict__ in, double* __restrict__ out,
+__global__ __launch_bounds__(256, (NP >= LN_BWD_COLS_ONE_WAVE_FROM ? 1 : LN_BWD_COLS_WAVES)) void kc_bwd_cols(const double* __restrict__ coef, const double* __restrict__ in, double* __restrict__ out,
                                            size_t xs, int ncols, const FilterDev* filt, double* partial, const double* ranks,
                                            int slice, const double* fg) {
     // four independent waves per workgroup, each with a partial-sum slot of its own (grid.x * 4 <= LN_GX)
@@ -420,7 +423,7 @@ constexpr unsigned LN_BUCKET_CAP = 4096;
 #define LN_RUNS 8        // runs a wave fetches at a time: 16 loads in flight
 #endif
 template <int NP, int M>
-__global__ __launch_bounds__(256, (NP >= LN_ONE_WAVE_FROM ? 1 : LN_BWD_COLS_WAVES)) void kc_bwd_cols_regions(
+__global__ __launch_bounds__(256, (NP >= LN_BWD_COLS_ONE_WAVE_FROM ? 1 : LN_BWD_COLS_WAVES)) void kc_bwd_cols_regions(
     const double* __restrict__ in, double* __restrict__ out, size_t xs, int ncols, const FilterDev* filt, double* partial,
     const unsigned* __restrict__ pairs, const unsigned short* __restrict__ snap, const unsigned* __restrict__ meta_all,
     int meta_stride, int nbe, int ib, const double* fg, const unsigned* flag) {
@@ -652,8 +655,11 @@ __global__ LN_BOUNDS(256) void kr_fwd_rows(const double* __restrict__ in, double
 
 // Filter gradient over the rows (no errors on the input: the last pass of the training step): errors on
 // the row coefficients (coef) and the rows themselves (in).  grid (tiles per example <= LN_GX, examples).
+#ifndef LN_GRAD_ROWS_ONE_WAVE_FROM
+#define LN_GRAD_ROWS_ONE_WAVE_FROM LN_ONE_WAVE_FROM
+#endif
 template <int NP, int M>
-__global__ LN_BOUNDS(256) void kr_grad_rows(const double* __restrict__ coef, const double* __restrict__ in, size_t xs, int R,
+__global__ __launch_bounds__(256, (NP >= LN_GRAD_ROWS_ONE_WAVE_FROM ? 1 : 2)) void kr_grad_rows(const double* __restrict__ coef, const double* __restrict__ in, size_t xs, int R,
                                             const FilterDev* filt, double* partial) {
     using T = LineTile<M>;
     constexpr int PER_WAVE = T::ROWS / 4;
