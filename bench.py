@@ -47,9 +47,9 @@ ROTATE = {"2d64": 3, "2d64n16": 3, "1d1024": 10, "2d512": 1, "2d512n16": 1, "1d1
 LIMITER = {
     "2d64": "VALU/LDS issue: the 4096-key bitonic sort of the Gini ranks is about half of the kernel's cycles",
     "2d64n16": "VALU issue (filter cascade and sort) with one wave per SIMD",
-    "1d1024": "VALU issue: the Gini phase (sort and ranks) is most of the kernel's instructions",
-    "2d512": "HBM passes of the per-example ranking and of the four line-transform kernels",
-    "2d512n16": "LDS crossbar: the cross-lane gathers of the six replicated small levels of every line, 16 per level and direction",
+    "1d1024": "VALU/LDS issue at two waves per SIMD: the sort's exchanges through LDS and the filter cascade",
+    "2d512": "HBM passes of the four line-transform kernels; the per-bucket LDS sort of the ranking (instruction issue, barriers)",
+    "2d512n16": "vector issue of the two backward line kernels (one and two waves per SIMD), then the ranking",
     "1d1m": "kernel count and tail latency: 8 signals per step give each launch little work",
     "1d1mb64": "HBM passes of the level-by-level transform (32 taps) and of the ranking",
 }
