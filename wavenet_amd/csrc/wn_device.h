@@ -394,11 +394,13 @@ __device__ __forceinline__ void sort_run(double* keys, unsigned t) {
 // lanes of a pair fetch the partner's key and keep the minimum or the maximum.  Only the
 // sub-stages on wave bits go through LDS (sort_run on the top window).
 // ---------------------------------------------------------------------------------------------
+// CTRL: a permutation (every lane has a source).  Zero for "no source" plus bound_ctrl: the destination needs no
+// initialising move.
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 

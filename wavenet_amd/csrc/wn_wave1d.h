@@ -33,15 +33,17 @@ __device__ __forceinline__ double w1d_lane(double v, int src) {
 }
 // The wave rotated by one lane: lane i receives lane i - 1 (ror) or lane i + 1 (rol), modulo 64.  A DPP move in the
 // vector pipeline: no LDS instruction, unlike ds_bpermute, and the periodic boundary comes with it.  Every lane of
-// the wave must be active.
+// the wave must be active.  (Here and below: a zero for lanes without a source AND bound_ctrl, which says the same
+// thing twice -- in that form the compiler knows the destination's old value is dead and does not emit a move that
+// sets it to zero in front of every DPP move.)
 __device__ __forceinline__ double w1d_ror1(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x13C, 0xf, 0xf, false);   // wave_ror:1
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x13C, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x13C, 0xf, 0xf, true);   // wave_ror:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x13C, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double w1d_rol1(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x134, 0xf, 0xf, false);   // wave_rol:1
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x134, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x134, 0xf, 0xf, true);   // wave_rol:1
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x134, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // v of lane (lane - D) mod 64: neighbours at distance 1 and 2 by rotations, the others through ds_bpermute
@@ -67,16 +69,16 @@ __device__ __forceinline__ double w1d_uniform(double v) {
 template <int N>
 __device__ __forceinline__ double w1d_row_ror(double v) {
     static_assert(N >= 1 && N <= 15, "row_ror takes 1..15");
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // Permutation inside every group of four lanes: lane 4 g + i receives lane 4 g + {A, B, C, D}[i] (DPP quad_perm).
 template <int A, int B, int C, int D>
 __device__ __forceinline__ double w1d_quad(double v) {
     constexpr int ctrl = A | (B << 2) | (C << 4) | (D << 6);
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // out[t] = v of lane (lane + S0 + t), t < CNT, for a value that is periodic in the lane number with period P (a
