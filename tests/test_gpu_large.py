@@ -53,7 +53,8 @@ def filt_for(N, seed=0):
 
 @pytest.mark.parametrize("R,C,N", [(128, 64, 4), (64, 128, 2), (8192, 1, 16), (1, 8192, 6), (256, 128, 32), (2, 4096, 8),
                                    (512, 512, 4), (512, 16, 8), (512, 32, 32),
-                                   (1 << 17, 1, 32), (1 << 16, 1, 16), (1 << 16, 2, 16)])      # long lines: several levels per launch
+                                   (1 << 17, 1, 32), (1 << 16, 1, 16), (1 << 16, 2, 16),      # long lines: several levels per launch
+                                   (1 << 16, 1, 28), (1 << 16, 1, 30), (1 << 15, 1, 18)])     # 32 compiled taps, 2 / 1 / 7 of padding in front
 def test_forward_inverse_backprop(ctx, oracle, R, C, N):
     import torch
     B = 2
@@ -111,7 +112,7 @@ def test_sparse_term_and_deriv(ctx, oracle, n):
                                      (512, 128, 8, 2), (16, 512, 4, 3), (64, 512, 16, 2), (128, 512, 32, 2),
                                      (1024, 512, 2, 2), (32, 512, 6, 40), (128, 128, 4, 3), (256, 256, 8, 2),
                                      (1024, 128, 2, 2), (128, 1024, 16, 2), (256, 64, 32, 2), (1024, 1024, 4, 1),
-                                     (2048, 256, 4, 2), (8, 1024, 6, 5)])
+                                     (2048, 256, 4, 2), (8, 1024, 6, 5), (1 << 17, 1, 28, 2), (1 << 17, 1, 30, 2)])
 def test_train_batch(ctx, oracle, R, C, N, B):
     """Batch sums and per-example values of the full step; 512x512 and 2^20 x 1 are the full sizes of the
     data-parallel configurations."""

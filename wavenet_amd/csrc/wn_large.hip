@@ -61,14 +61,37 @@ __device__ __forceinline__ void decode(int w, int lgNL, int lgInner, int lanesOn
     else              { k = w & ((1 << lgInner) - 1); line = w >> lgInner; }
 }
 
+
+// The taps for the lifetime of a kernel: values that are the same in every lane, which the compiler keeps in scalar
+// registers.  Two filters of 32 taps are 128 of those, more than a wave has: the compiler then parks them in the lanes
+// of vector registers and fetches every tap back with a v_readlane in front of its multiply-add -- as many moves as
+// arithmetic.  FROM_A: the high-pass taps are not loaded but written as what they are, b[j] = (-1)^j a[NP - 1 - j]
+// (src/HighpassOperator.cxx:14-18; a negated operand costs nothing), which leaves 64 registers to hold.  The stored
+// b carries the parity of the TRUE tap index, j minus the padding in front of the filter: FROM_A is for an even
+// padding only (the host code sends the other case to the kernels that load b).  Padded entries come out as +-0
+// instead of +0, which no sum can tell apart.
+template <int NP, bool FROM_A = false>
+__device__ __forceinline__ void load_taps(const FilterDev* filt, double (&a)[NP], double (&b)[NP]) {
+#pragma unroll
+    for (int j = 0; j < NP; j++) a[j] = filt->a[j];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        if constexpr (FROM_A) b[j] = (j & 1) ? -a[NP - 1 - j] : a[NP - 1 - j];
+        else b[j] = filt->b[j];
+    }
+}
+#ifndef WN_TAPS_FROM_A_ABOVE
+#define WN_TAPS_FROM_A_ABOVE 16
+#endif
+constexpr bool taps_from_a(int NP) { return NP > WN_TAPS_FROM_A_ABOVE; }   // the tap counts whose LDS-staged and tail kernels use FROM_A
+
 // lo[k] = sum_j a[j] in[(N/2 + 2k - j) mod len], hi[k] with b; one level, whole chunk (grid.y = example).
 template <int NP>
 __global__ __launch_bounds__(BT) void kb_fwd_level(const double* __restrict__ in, double* __restrict__ lo,
                                                    double* __restrict__ hi, size_t xs, Geom g, int lgHalf,
                                                    const FilterDev* filt) {
     double a[NP], b[NP];
-#pragma unroll
-    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    load_taps<NP>(filt, a, b);
     const size_t off = (size_t)blockIdx.y * xs;
     const int W = 1 << (g.lgNL + lgHalf), lmask = (2 << lgHalf) - 1;
     for (int w = blockIdx.x * BT + threadIdx.x; w < W; w += gridDim.x * BT) {
@@ -135,8 +158,7 @@ __global__ __launch_bounds__(BT) void kb_prop_level(const double* __restrict__ l
                                                     double* __restrict__ out, size_t xs, Geom g, int lgLen,
                                                     const FilterDev* filt) {
     double a[NP], b[NP];
-#pragma unroll
-    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    load_taps<NP>(filt, a, b);
     constexpr int S = NP / 2;
     constexpr int JE = S & 1, JO = (S + 1) & 1;
     constexpr int CE = (JE - S) / 2, CO = (1 + JO - S) / 2;
@@ -168,8 +190,7 @@ __global__ __launch_bounds__(BT) void kb_bwd_level(const double* __restrict__ lp
                                                    int lgLen, const FilterDev* filt, double* partial, int pgx) {
     __shared__ double red[(BT / 64) * 2 * NP];
     double a[NP], b[NP];
-#pragma unroll
-    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    load_taps<NP>(filt, a, b);
     double gL[NP], gH[NP];
 #pragma unroll
     for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
@@ -240,8 +261,7 @@ __global__ __launch_bounds__(LT) void kb_fwd_level_lds(const double* __restrict_
                                                        size_t xs, Geom g, int lgHalf, const FilterDev* filt) {
     __shared__ __attribute__((aligned(16))) double tile[2 * LT + NP];
     double a[NP], b[NP];
-#pragma unroll
-    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    load_taps<NP, taps_from_a(NP)>(filt, a, b);
     const int w0 = blockIdx.x * LT;
     const int line = w0 >> lgHalf, k0 = w0 & ((1 << lgHalf) - 1);
     const size_t off = (size_t)blockIdx.y * xs + (size_t)line * g.ls;
@@ -319,8 +339,7 @@ __global__ __launch_bounds__(LT) void kb_fwd_levels_lds(const double* __restrict
     using F = FwdFused<NP, NLEV>;
     extern __shared__ __attribute__((aligned(16))) double fused_lds[];
     double a[NP], b[NP];
-#pragma unroll
-    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    load_taps<NP, taps_from_a(NP)>(filt, a, b);
     const int lgLow = i - (NLEV - 1);                                // outputs per line of the lowest stage: 2^lgLow
     const int w0 = blockIdx.x * LT;
     const int line = w0 >> lgLow, K0 = w0 & ((1 << lgLow) - 1);
@@ -352,8 +371,7 @@ __global__ __launch_bounds__(LT) void kb_bwd_level_lds(const double* __restrict_
     __shared__ double tl[EW], th[EW];
     __shared__ double red[(LT / 64) * 2 * NP];
     double a[NP], b[NP];
-#pragma unroll
-    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    load_taps<NP, taps_from_a(NP)>(filt, a, b);
     double gL[NP], gH[NP];
 #pragma unroll
     for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
@@ -432,8 +450,7 @@ template <int NP>
 __global__ __launch_bounds__(TAIL_T) void kb_fwd_tail(const double* __restrict__ in, double* P, double* out, size_t xs, Geom g,
                                                       int lgLen, const FilterDev* filt) {
     double a[NP], b[NP];
-#pragma unroll
-    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    load_taps<NP, taps_from_a(NP)>(filt, a, b);
     const size_t off = (size_t)blockIdx.y * xs + (size_t)blockIdx.x * g.ls;
     fwd_pass<NP, TAIL_T>(in + off, P + off, out + off, 1, 0, 0, lgLen, false, a, b, (int)threadIdx.x);
 }
@@ -446,8 +463,7 @@ __global__ __launch_bounds__(TAIL_T) void kb_bwd_tail(double* D, const double* a
                                                       const FilterDev* filt, double* partial, int pgx) {
     __shared__ double red[(TAIL_T / 64) * 2 * NP];
     double a[NP], b[NP];
-#pragma unroll
-    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    load_taps<NP, taps_from_a(NP)>(filt, a, b);
     double gL[NP], gH[NP];
 #pragma unroll
     for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
@@ -474,8 +490,7 @@ __global__ __launch_bounds__(TAIL_LDS_T) void kb_fwd_tail_lds(const double* __re
     double* sP = sIn + len;
     double* sOut = sP + len;
     double a[NP], b[NP];
-#pragma unroll
-    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    load_taps<NP, taps_from_a(NP)>(filt, a, b);
     const size_t off = (size_t)blockIdx.y * xs + (size_t)blockIdx.x * g.ls;
     for (int i = 2 * tid; i < len; i += 2 * TAIL_LDS_T) *reinterpret_cast<double2*>(sIn + i) = *reinterpret_cast<const double2*>(in + off + i);
     __syncthreads();
@@ -496,8 +511,7 @@ __global__ __launch_bounds__(TAIL_LDS_T) void kb_bwd_tail_lds(double* D, const d
     double* sAct = sD + len;
     double* sP = sAct + len;
     double a[NP], b[NP];
-#pragma unroll
-    for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+    load_taps<NP, taps_from_a(NP)>(filt, a, b);
     double gL[NP], gH[NP];
 #pragma unroll
     for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
@@ -890,20 +904,28 @@ inline dim3 grid_for(int items, int B, int cap = 4096) {
 bool tail_in_lds(const wn_context* ctx, const Geom& g, int B, int lgTail) {
     return ((long long)B << g.lgNL) <= ctx->numCU && lgTail >= 8 && lgTail <= TAIL_LG;
 }
+// The LDS-staged and tail kernels write the high-pass taps from the low-pass ones where taps_from_a says so, which
+// holds for an even padding in front of the filter (load_taps); a filter with an odd one goes level by level.
+template <int NP>
+bool staged_kernels_fit(const wn_context* ctx) {
+    return !taps_from_a(NP) || (((NP - ctx->N) / 2) & 1) == 0;
+}
+
 template <int NP>
 int fwd_pass_big(wn_context* ctx, const double* in, double* P, double* out, int B, size_t n, Geom g) {
     hipStream_t st = ctx->stream;
+    const bool staged = staged_kernels_fit<NP>(ctx);
     if (g.lgLen == 0) {
         WN_HIP(ctx, hipMemcpyAsync(out, in, (size_t)B * n * sizeof(double), hipMemcpyDeviceToDevice, st));
         WN_HIP(ctx, hipMemsetAsync(P, 0, (size_t)B * n * sizeof(double), st));
         return WN_OK;
     }
     // contiguous lines: the levels below 2^TAIL_LG samples in one launch
-    const int tail = (g.es == 1 && !g.lanesOnLines && ctx->wave64 && (g.lgLen > TAIL_LG || NP <= 8)) ? std::min(g.lgLen, TAIL_LG) : 0;
+    const int tail = (staged && g.es == 1 && !g.lanesOnLines && ctx->wave64 && (g.lgLen > TAIL_LG || NP <= 8)) ? std::min(g.lgLen, TAIL_LG) : 0;
     for (int i = g.lgLen - 1; i >= tail; i--) {
         const double* src = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i) * g.es;
         // long contiguous lines: three (or two) levels per launch while that many are left above the tail
-        if (NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && i - 1 >= tail && (1 << (i - 1)) >= 16 * LT) {
+        if (staged && NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && i - 1 >= tail && (1 << (i - 1)) >= 16 * LT) {
             const int nlev = (i - 2 >= tail && (1 << (i - 2)) >= 16 * LT) ? 3 : 2;
             const dim3 grid((1u << (g.lgNL + i - (nlev - 1))) / LT, B);
             if (nlev == 3) {
@@ -916,7 +938,7 @@ int fwd_pass_big(wn_context* ctx, const double* in, double* P, double* out, int 
             i -= nlev - 1;
             continue;
         }
-        if (NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && (1 << i) >= LT) {
+        if (staged && NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && (1 << i) >= LT) {
             hipLaunchKernelGGL(kb_fwd_level_lds<NP>, dim3((1u << (g.lgNL + i)) / LT, B), dim3(LT), 0, st, src,
                                P + (size_t)(1 << i), out + (size_t)(1 << i), n, g, i, ctx->dfilt);
             continue;
@@ -954,7 +976,8 @@ int bwd_pass_big(wn_context* ctx, const double* coef, const double* in, const do
     // then have their levels below 2^TAIL_LG samples done in place by one launch; when that is the whole
     // pass, its result -- the errors on the lines -- is in coef.
     int first = 0;
-    if (coefScratch && partial && g.es == 1 && !g.lanesOnLines && ctx->wave64 && (g.lgLen > TAIL_LG || (NP <= 8 && lastPropagate))) {
+    const bool staged = staged_kernels_fit<NP>(ctx);
+    if (staged && coefScratch && partial && g.es == 1 && !g.lanesOnLines && ctx->wave64 && (g.lgLen > TAIL_LG || (NP <= 8 && lastPropagate))) {
         first = std::min(g.lgLen, TAIL_LG);
         const double* act = (first == g.lgLen) ? in : P + ((size_t)1 << first);
         if (tail_in_lds(ctx, g, B, first) && (1 << g.lgNL) <= pgx) {
@@ -970,7 +993,7 @@ int bwd_pass_big(wn_context* ctx, const double* coef, const double* in, const do
     for (int i = first; i < g.lgLen; i++) {
         const double* hp = coef + (size_t)(1 << i) * g.es;
         const bool propagate = (i != g.lgLen - 1 || lastPropagate);
-        if (partial && NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && (1 << i) >= LT) {
+        if (staged && partial && NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && (1 << i) >= LT) {
             const double* act = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i);
             const dim3 grid((unsigned)std::min<size_t>(((size_t)1 << (g.lgNL + i)) / LT, pgx), B);
             if (propagate) {
