@@ -72,15 +72,16 @@ __device__ __forceinline__ void copy_out(double* __restrict__ dst, const double*
 }
 
 // Reduce the per-thread window sums to the N-tap gradient of this example.  Thread k' < NP
-// returns tap k' - d of the (padded) filter; other threads return 0.
+// returns tap k' - d of the (padded) filter; other threads return 0.  sg: the sign the high-pass
+// window sums carry (-1 where a kernel worked with the high-pass taps times -1, k_train below).
 template <int NP, int T>
 __device__ __forceinline__ double reduce_gradient(const double (&gL)[NP], const double (&gH)[NP],
-                                                  const FilterDev* filt, double* red, int tid) {
+                                                  const FilterDev* filt, double* red, int tid, double sg = 1.0) {
     constexpr int NWV = T / 64;
     double cp[NP];
 #pragma unroll
     for (int k = 0; k < NP; k++) {
-        cp[k] = filt->vL[k] * gL[k] + filt->sH[k] * gH[NP - 1 - k];
+        cp[k] = filt->vL[k] * gL[k] + (sg * filt->sH[k]) * gH[NP - 1 - k];
         cp[k] = wave_sum(cp[k]);
     }
     __syncthreads();
@@ -124,6 +125,15 @@ __global__ __launch_bounds__(T) void k_train(FusedArgs A) {
 #pragma unroll
     for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
     const int N = filt->N, d = filt->d;
+    // Above 16 taps the high-pass taps are held as signed low-pass taps, b'[j] = (-1)^j a[NP - 1 - j] = sg b with
+    // sg = (-1)^d, which halves the registers for taps; the signs of coefficients and errors that follow from it
+    // cancel on the way to the gradient, as spelled out in k_train64 (wn_wave64.h), and the results are the same bits.
+    constexpr bool B_FROM_A = (NP > 16);
+    if constexpr (B_FROM_A) {
+#pragma unroll
+        for (int j = 0; j < NP; j++) b[j] = (j & 1) ? -a[NP - 1 - j] : a[NP - 1 - j];
+    }
+    const double sg = (B_FROM_A && (d & 1)) ? -1.0 : 1.0;
 
     double accG = 0, accS = 0, accBad = 0;
     double xpre[K];
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(T) void k_train(FusedArgs A) {
             fwd_pass_lo<NP, T>(bufX, bufP, R, 1, lgR, lgC, true, a, tid);
             bwd_pass<NP, T, K, true>(bufY, bufX, bufP, R, 1, lgR, lgC, true, false, a, b, gL, gH, tid);  // rows (:701-708)
         }
-        const double ge = reduce_gradient<NP, T>(gL, gH, filt, red, tid);
+        const double ge = reduce_gradient<NP, T>(gL, gH, filt, red, tid, sg);
         const int k = tid - d;
         if (tid < NP && k >= 0 && k < N) {
             accG += ge;

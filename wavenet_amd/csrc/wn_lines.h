@@ -746,6 +746,13 @@ __global__ __launch_bounds__(64, 2) void k_train_line(FusedArgs A) {
     double a[NP], b[NP];
     ln_load_taps<NP>(filt, a, b);
     const int N = filt->N, dpad = filt->d;
+    // above 16 taps: the high-pass taps as signed low-pass taps (k_train1d1024, wn_wave1d.h, has the reasoning)
+    constexpr bool B_FROM_A = (NP > 16);
+    if constexpr (B_FROM_A) {
+#pragma unroll
+        for (int j = 0; j < NP; j++) b[j] = (j & 1) ? -a[NP - 1 - j] : a[NP - 1 - j];
+    }
+    const double sg = (B_FROM_A && (dpad & 1)) ? -1.0 : 1.0;
     double accG = 0, accS = 0, accBad = 0;
     for (int e = blockIdx.x; e < A.B; e += gridDim.x) {
         LinePyramid<M> p;
@@ -767,7 +774,7 @@ __global__ __launch_bounds__(64, 2) void k_train_line(FusedArgs A) {
         double mine = 0;
 #pragma unroll
         for (int kp = 0; kp < NP; kp++) {
-            double c = filt->vL[kp] * gL[kp] + filt->sH[kp] * gH[NP - 1 - kp];
+            double c = filt->vL[kp] * gL[kp] + (sg * filt->sH[kp]) * gH[NP - 1 - kp];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
             if (lane == kp) mine = c;

@@ -626,6 +626,22 @@ __global__ __launch_bounds__(256, W1D_WAVES) void k_train1d1024(FusedArgs A) {
         for (int j = 0; j < NP; j++) { a[j] = w1d_uniform(a[j]); b[j] = w1d_uniform(b[j]); }
     }
     const int N = filt->N, dpad = filt->d;
+#ifndef W1D_B_LOADED
+    // The high-pass taps are the low-pass taps reversed with alternating signs (src/HighpassOperator.cxx:14-18).  The
+    // kernel does not hold the stored b but writes b'[j] = (-1)^j a[NP - 1 - j], a negated operand where the sign is
+    // minus: half the registers for taps (two filters of 16 or 32 taps do not fit the scalar registers, and the
+    // compiler then fetches spilled taps back lane by lane in front of the multiply-adds).  The stored b carries the
+    // parity of the TRUE tap index: b = sg b' with sg = (-1)^(padding in front of the filter).  Nothing is corrected
+    // for that on the way: the high-pass coefficients come out times sg, the Gini term does not see the sign of a
+    // coefficient and its derivative is odd in it, so the errors on them are times sg as well, the errors propagated
+    // to the low-pass side are products of the two, and the high-pass window sums gH are times sg -- which the sign
+    // table takes back below.  A negation is exact, so every number that leaves the kernel is the same bit for bit.
+#pragma unroll
+    for (int j = 0; j < NP; j++) b[j] = (j & 1) ? -a[NP - 1 - j] : a[NP - 1 - j];
+    const double sg = (dpad & 1) ? -1.0 : 1.0;
+#else
+    const double sg = 1.0;
+#endif
 
     double accG = 0, accS = 0, accBad = 0;
     for (int e = blockIdx.x * 4 + wave; e < A.B; e += gridDim.x * 4) {
@@ -752,7 +768,7 @@ __global__ __launch_bounds__(256, W1D_WAVES) void k_train1d1024(FusedArgs A) {
         double mine = 0;
 #pragma unroll
         for (int kp = 0; kp < NP; kp++) {
-            double c = filt->vL[kp] * gL[kp] + filt->sH[kp] * gH[NP - 1 - kp];
+            double c = filt->vL[kp] * gL[kp] + (sg * filt->sH[kp]) * gH[NP - 1 - kp];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
             if (lane == kp) mine = c;

@@ -637,6 +637,10 @@ __global__ __launch_bounds__(256, 1) void k_cost64(FusedArgs A) {
         double a[NP], b[NP];
 #pragma unroll
         for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
+        if constexpr (NP > 16) {   // as in k_train64: only the signs of coefficients change, which the Gini term does not see
+#pragma unroll
+            for (int j = 0; j < NP; j++) b[j] = (j & 1) ? -a[NP - 1 - j] : a[NP - 1 - j];
+        }
         unsigned tile_off = (unsigned)wave * W64_TILE;
         asm volatile("" : "+s"(tile_off));
         double* tile = smem + tile_off;
@@ -665,6 +669,18 @@ __global__ __launch_bounds__(256, 1) void k_train64(FusedArgs A) {
 #pragma unroll
     for (int j = 0; j < NP; j++) { a[j] = filt->a[j]; b[j] = filt->b[j]; }
     const int N = filt->N, dpad = filt->d;
+    // Above 16 taps (at 16 it measures the same) the kernel holds the high-pass taps as signed low-pass taps, b'[j] = (-1)^j a[NP - 1 - j], not
+    // the stored b = sg b', sg = (-1)^(padding in front of the filter): half the registers for taps.  No sign is put
+    // right on the way: coefficient (r, c) comes out times s_r s_c, with s = sg on the high-pass indices and 1 on
+    // index 0; the Gini term does not see that and its derivative is odd in a coefficient, so the errors carry the
+    // same signs, the propagation multiplies two of them, and the high-pass window sums come out times sg, which the
+    // sign table takes back.  Negations are exact: what leaves the kernel is the same bit for bit (k_train1d1024 too).
+    constexpr bool B_FROM_A = (NP > 16);
+    if constexpr (B_FROM_A) {
+#pragma unroll
+        for (int j = 0; j < NP; j++) b[j] = (j & 1) ? -a[NP - 1 - j] : a[NP - 1 - j];
+    }
+    const double sg = (B_FROM_A && (dpad & 1)) ? -1.0 : 1.0;
 
     double accG = 0, accS = 0, accBad = 0;
     const int nslots = gridDim.x * 4;
@@ -704,7 +720,7 @@ __global__ __launch_bounds__(256, 1) void k_train64(FusedArgs A) {
         double mine = 0;
 #pragma unroll
         for (int kp = 0; kp < NP; kp++) {
-            double c = filt->vL[kp] * gL[kp] + filt->sH[kp] * gH[NP - 1 - kp];
+            double c = filt->vL[kp] * gL[kp] + (sg * filt->sH[kp]) * gH[NP - 1 - kp];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
             if (lane == kp) mine = c;
