@@ -21,7 +21,7 @@ line = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
 parts = []
 for r in rows:
     n = r["Name"].replace("void ", "")
-    n = n[:n.find("(")] if "(" in n else n
+    n = n.replace("(anonymous namespace)::", ""); n = n[:n.find("(")] if "(" in n else n
     n = n.replace("wn::", "").replace("rk::", "").replace("(anonymous namespace)::", "")
     if pat.search(n):
         parts.append("%s %.0f" % (n, float(r["AverageNs"]) / 1e3))

@@ -85,6 +85,31 @@ __device__ __forceinline__ void load_taps(const FilterDev* filt, double (&a)[NP]
 #endif
 constexpr bool taps_from_a(int NP) { return NP > WN_TAPS_FROM_A_ABOVE; }   // the tap counts whose LDS-staged and tail kernels use FROM_A
 
+// The ranking wants the largest exponent word (upper 32 bits of |c|) among an example's coefficients before anything
+// else (kr_max, wn_rank.h: one more pass over them).  The forward kernels of long contiguous lines keep track of it
+// for the coefficients they write, and every workgroup leaves its maximum in a slot of its own, kparts[example *
+// stride + slot0 + blockIdx.x]; kr_hist takes the maximum over an example's slots.  (Not an atomic on one word per
+// example: atomics of device scope are carried out behind the L2s, one after the other per address -- 512 of them per
+// example and launch were a fifth of the forward kernel's time, and a look at the word first, which has to be of device
+// scope as well, six times its time.)
+struct KmaxSlots {
+    unsigned* parts;     // null: not wanted
+    int stride, slot0;   // slots per example; first slot of this launch
+};
+__device__ __forceinline__ unsigned exponent_word(double c) { return (unsigned)__double2hiint(c) & 0x7FFFFFFFu; }
+template <int T>
+__device__ __forceinline__ void leave_kmax(unsigned m, const KmaxSlots& ks, unsigned* wmax /* T / 64 words of LDS */) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < T / 64; w++) m = max(m, wmax[w]);
+        ks.parts[(size_t)blockIdx.y * ks.stride + ks.slot0 + blockIdx.x] = m;
+    }
+}
+
 // lo[k] = sum_j a[j] in[(N/2 + 2k - j) mod len], hi[k] with b; one level, whole chunk (grid.y = example).
 template <int NP>
 __global__ __launch_bounds__(BT) void kb_fwd_level(const double* __restrict__ in, double* __restrict__ lo,
@@ -258,8 +283,9 @@ __device__ __forceinline__ void read_window(const double* tile, double (&win)[NP
 // kb_fwd_level for contiguous lines with at least LT outputs: grid (lines * half / LT, examples)
 template <int NP>
 __global__ __launch_bounds__(LT) void kb_fwd_level_lds(const double* __restrict__ in, double* __restrict__ lo, double* __restrict__ hi,
-                                                       size_t xs, Geom g, int lgHalf, const FilterDev* filt) {
+                                                       size_t xs, Geom g, int lgHalf, const FilterDev* filt, KmaxSlots ks) {
     __shared__ __attribute__((aligned(16))) double tile[2 * LT + NP];
+    __shared__ unsigned wmax[LT / 64];
     double a[NP], b[NP];
     load_taps<NP, taps_from_a(NP)>(filt, a, b);
     const int w0 = blockIdx.x * LT;
@@ -277,6 +303,7 @@ __global__ __launch_bounds__(LT) void kb_fwd_level_lds(const double* __restrict_
     }
     lo[off + k0 + threadIdx.x] = sl;
     hi[off + k0 + threadIdx.x] = sh;
+    if (ks.parts) leave_kmax<LT>(exponent_word(sh), ks, wmax);
 }
 
 // NLEV consecutive levels of kb_fwd_level_lds in one launch: a workgroup produces LT outputs of the lowest of them and
@@ -302,7 +329,7 @@ struct FwdFused {
 
 template <int NP, int NLEV, int S>
 __device__ __forceinline__ void fwd_fused_stage(const double* src, double* tiles, double* P, double* out, size_t off, int K0, int i,
-                                                const double (&a)[NP], const double (&b)[NP]) {
+                                                const double (&a)[NP], const double (&b)[NP], unsigned& kmine) {
     using F = FwdFused<NP, NLEV>;
     constexpr int NEED = F::need(S), OWN = LT << (NLEV - 1 - S), OWN_OFF = -F::first(S);
     const int lvl = i - S;
@@ -325,19 +352,21 @@ __device__ __forceinline__ void fwd_fused_stage(const double* src, double* tiles
         if (o >= 0 && o < OWN) {
             P[off + ((size_t)1 << lvl) + own0 + o] = sl;
             out[off + ((size_t)1 << lvl) + own0 + o] = sh;
+            kmine = max(kmine, exponent_word(sh));
         }
     }
     if constexpr (S < NLEV - 1) {
         __syncthreads();
-        fwd_fused_stage<NP, NLEV, S + 1>(tiles, tiles + NEED + 1, P, out, off, K0, i, a, b);
+        fwd_fused_stage<NP, NLEV, S + 1>(tiles, tiles + NEED + 1, P, out, off, K0, i, a, b, kmine);
     }
 }
 
 template <int NP, int NLEV>
 __global__ __launch_bounds__(LT) void kb_fwd_levels_lds(const double* __restrict__ in, double* __restrict__ P, double* __restrict__ out,
-                                                        size_t xs, Geom g, int i, const FilterDev* filt) {
+                                                        size_t xs, Geom g, int i, const FilterDev* filt, KmaxSlots ks) {
     using F = FwdFused<NP, NLEV>;
     extern __shared__ __attribute__((aligned(16))) double fused_lds[];
+    __shared__ unsigned wmax[LT / 64];
     double a[NP], b[NP];
     load_taps<NP, taps_from_a(NP)>(filt, a, b);
     const int lgLow = i - (NLEV - 1);                                // outputs per line of the lowest stage: 2^lgLow
@@ -348,7 +377,9 @@ __global__ __launch_bounds__(LT) void kb_fwd_levels_lds(const double* __restrict
     const int first = (K0 << NLEV) + F::IN_FIRST, mask = (2 << i) - 1;
     for (int t = threadIdx.x; t < F::IN + 1; t += LT) fused_lds[t] = in[off + ((first + t) & mask)];
     __syncthreads();
-    fwd_fused_stage<NP, NLEV, 0>(fused_lds, fused_lds + F::IN + 1, P, out, off, K0, i, a, b);
+    unsigned kmine = 0;
+    fwd_fused_stage<NP, NLEV, 0>(fused_lds, fused_lds + F::IN + 1, P, out, off, K0, i, a, b, kmine);
+    if (ks.parts) leave_kmax<LT>(kmine, ks, wmax);
 }
 
 // kb_bwd_level / kb_grad_level (PROP false) for contiguous lines with at least LT errors per line:
@@ -448,11 +479,19 @@ constexpr int TAIL_LG = 12, TAIL_T = 256;
 // in: the level's input (2^lgLen samples per line); P / out as in the level kernels.  grid (lines, examples).
 template <int NP>
 __global__ __launch_bounds__(TAIL_T) void kb_fwd_tail(const double* __restrict__ in, double* P, double* out, size_t xs, Geom g,
-                                                      int lgLen, const FilterDev* filt) {
+                                                      int lgLen, const FilterDev* filt, KmaxSlots ks) {
+    __shared__ unsigned wmax[TAIL_T / 64];
     double a[NP], b[NP];
     load_taps<NP, taps_from_a(NP)>(filt, a, b);
     const size_t off = (size_t)blockIdx.y * xs + (size_t)blockIdx.x * g.ls;
     fwd_pass<NP, TAIL_T>(in + off, P + off, out + off, 1, 0, 0, lgLen, false, a, b, (int)threadIdx.x);
+    if (ks.parts) {
+        // the coefficients this workgroup has just written (2^lgLen of them, the lowest low-pass value among them)
+        __syncthreads();
+        unsigned m = 0;
+        for (int i = threadIdx.x; i < (1 << lgLen); i += TAIL_T) m = max(m, exponent_word(out[off + i]));
+        leave_kmax<TAIL_T>(m, ks, wmax);
+    }
 }
 
 // D: errors on the coefficients of the lines, IN PLACE: on exit D[0 .. 2^lgLen) of every line holds the errors
@@ -483,8 +522,9 @@ __global__ __launch_bounds__(TAIL_T) void kb_bwd_tail(double* D, const double* a
 constexpr int TAIL_LDS_T = 512;
 template <int NP>
 __global__ __launch_bounds__(TAIL_LDS_T) void kb_fwd_tail_lds(const double* __restrict__ in, double* P, double* out, size_t xs, Geom g,
-                                                              int lgLen, const FilterDev* filt) {
+                                                              int lgLen, const FilterDev* filt, KmaxSlots ks) {
     extern __shared__ __attribute__((aligned(16))) double tail_lds[];
+    __shared__ unsigned wmax[TAIL_LDS_T / 64];
     const int len = 1 << lgLen, tid = threadIdx.x;
     double* sIn = tail_lds;
     double* sP = sIn + len;
@@ -495,10 +535,14 @@ __global__ __launch_bounds__(TAIL_LDS_T) void kb_fwd_tail_lds(const double* __re
     for (int i = 2 * tid; i < len; i += 2 * TAIL_LDS_T) *reinterpret_cast<double2*>(sIn + i) = *reinterpret_cast<const double2*>(in + off + i);
     __syncthreads();
     fwd_pass<NP, TAIL_LDS_T>(sIn, sP, sOut, 1, 0, 0, lgLen, false, a, b, tid);
+    unsigned m = 0;
     for (int i = 2 * tid; i < len; i += 2 * TAIL_LDS_T) {
         *reinterpret_cast<double2*>(P + off + i) = *reinterpret_cast<const double2*>(sP + i);
-        *reinterpret_cast<double2*>(out + off + i) = *reinterpret_cast<const double2*>(sOut + i);
+        const double2 c = *reinterpret_cast<const double2*>(sOut + i);
+        *reinterpret_cast<double2*>(out + off + i) = c;
+        m = max(m, max(exponent_word(c.x), exponent_word(c.y)));
     }
+    if (ks.parts) leave_kmax<TAIL_LDS_T>(m, ks, wmax);
 }
 
 template <int NP>
@@ -911,10 +955,18 @@ bool staged_kernels_fit(const wn_context* ctx) {
     return !taps_from_a(NP) || (((NP - ctx->N) / 2) & 1) == 0;
 }
 
+// kparts (may be null): kstride words per example in which the workgroups leave the largest exponent word of the
+// coefficients they wrote (KmaxSlots) when all the kernels are of the kind that can (long contiguous lines); *nparts
+// receives the number of slots written per example, 0 when they were not.
 template <int NP>
-int fwd_pass_big(wn_context* ctx, const double* in, double* P, double* out, int B, size_t n, Geom g) {
+int fwd_pass_big(wn_context* ctx, const double* in, double* P, double* out, int B, size_t n, Geom g, unsigned* kparts = nullptr,
+                 int kstride = 0, int* nparts = nullptr) {
     hipStream_t st = ctx->stream;
     const bool staged = staged_kernels_fit<NP>(ctx);
+    // every level by an LDS-staged kernel and the rest by a tail kernel?
+    if (!(staged && NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && ctx->wave64 && g.lgLen > TAIL_LG)) kparts = nullptr;
+    KmaxSlots ks{kparts, kstride, 0};
+    if (nparts) *nparts = 0;
     if (g.lgLen == 0) {
         WN_HIP(ctx, hipMemcpyAsync(out, in, (size_t)B * n * sizeof(double), hipMemcpyDeviceToDevice, st));
         WN_HIP(ctx, hipMemsetAsync(P, 0, (size_t)B * n * sizeof(double), st));
@@ -930,17 +982,19 @@ int fwd_pass_big(wn_context* ctx, const double* in, double* P, double* out, int 
             const dim3 grid((1u << (g.lgNL + i - (nlev - 1))) / LT, B);
             if (nlev == 3) {
                 const size_t lds = FwdFused<NP, 3>::lds_doubles() * sizeof(double);
-                hipLaunchKernelGGL((kb_fwd_levels_lds<NP, 3>), grid, dim3(LT), lds, st, src, P, out, n, g, i, ctx->dfilt);
+                hipLaunchKernelGGL((kb_fwd_levels_lds<NP, 3>), grid, dim3(LT), lds, st, src, P, out, n, g, i, ctx->dfilt, ks);
             } else {
                 const size_t lds = FwdFused<NP, 2>::lds_doubles() * sizeof(double);
-                hipLaunchKernelGGL((kb_fwd_levels_lds<NP, 2>), grid, dim3(LT), lds, st, src, P, out, n, g, i, ctx->dfilt);
+                hipLaunchKernelGGL((kb_fwd_levels_lds<NP, 2>), grid, dim3(LT), lds, st, src, P, out, n, g, i, ctx->dfilt, ks);
             }
+            ks.slot0 += (int)grid.x;
             i -= nlev - 1;
             continue;
         }
         if (staged && NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && (1 << i) >= LT) {
             hipLaunchKernelGGL(kb_fwd_level_lds<NP>, dim3((1u << (g.lgNL + i)) / LT, B), dim3(LT), 0, st, src,
-                               P + (size_t)(1 << i), out + (size_t)(1 << i), n, g, i, ctx->dfilt);
+                               P + (size_t)(1 << i), out + (size_t)(1 << i), n, g, i, ctx->dfilt, ks);
+            ks.slot0 += (int)((1u << (g.lgNL + i)) / LT);
             continue;
         }
         hipLaunchKernelGGL(kb_fwd_level<NP>, grid_for(1 << (g.lgNL + i), B), dim3(BT), 0, st, src,
@@ -951,14 +1005,19 @@ int fwd_pass_big(wn_context* ctx, const double* in, double* P, double* out, int 
         if (tail_in_lds(ctx, g, B, tail)) {
             const size_t lds = (size_t)3 * sizeof(double) << tail;
             WN_HIP(ctx, hipFuncSetAttribute((const void*)kb_fwd_tail_lds<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kb_fwd_tail_lds<NP>, dim3(1u << g.lgNL, B), dim3(TAIL_LDS_T), lds, st, src, P, out, n, g, tail, ctx->dfilt);
+            hipLaunchKernelGGL(kb_fwd_tail_lds<NP>, dim3(1u << g.lgNL, B), dim3(TAIL_LDS_T), lds, st, src, P, out, n, g, tail, ctx->dfilt, ks);
         } else {
-            hipLaunchKernelGGL(kb_fwd_tail<NP>, dim3(1u << g.lgNL, B), dim3(TAIL_T), 0, st, src, P, out, n, g, tail, ctx->dfilt);
+            hipLaunchKernelGGL(kb_fwd_tail<NP>, dim3(1u << g.lgNL, B), dim3(TAIL_T), 0, st, src, P, out, n, g, tail, ctx->dfilt, ks);
         }
+        ks.slot0 += 1 << g.lgNL;
     } else {
         hipLaunchKernelGGL(kb_finish_pass, grid_for(1 << g.lgNL, B), dim3(BT), 0, st, out, P, n, g);
     }
     WN_HIP(ctx, hipGetLastError());
+    if (ks.parts && nparts) {
+        if (ks.slot0 > kstride) return fail(ctx, WN_ERR_STATE, "more exponent-word slots than the caller sized");   // (they are sized from the same geometry)
+        *nparts = ks.slot0;
+    }
     return WN_OK;
 }
 
@@ -1074,6 +1133,11 @@ void rank_bins(size_t n, int* NF, int* lgBPO) {
 // them already (and its caller zeroed all B + 16 words before that).
 // What a consumer of (home index, rank) pairs needs to find them (kc_bwd_cols_regions, wn_lines.h).  want: the caller can
 // take pairs; used: pairs it is (32-bit ones in keysB, example e at word e * n; no ranks at home positions were written).
+// Where the producer of the coefficients left the largest exponent word per workgroup: count words per example, stride apart.
+struct KmaxParts {
+    const unsigned* parts;
+    int stride, count;
+};
 struct RankPairs {
     bool want = false, used = false;
     const unsigned* pairs = nullptr;
@@ -1087,7 +1151,7 @@ struct RankPairs {
 // examples but those it marked in hist_need[e].
 int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB, unsigned* idxA,
                  unsigned* idxB, double* fg, double* S_e, unsigned* kmax, bool kmax_ready, bool* ok, const unsigned** pending = nullptr,
-                 const unsigned* hist_need = nullptr, RankPairs* rp = nullptr) {
+                 const unsigned* hist_need = nullptr, RankPairs* rp = nullptr, const KmaxParts* kp = nullptr) {
     using namespace rk;
     *ok = false;
     int lgn = 0;
@@ -1121,14 +1185,17 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
     if (!kmax_ready) {
         // (the flag too: with kmax_ready the producer's caller has zeroed these B + 16 words before the producer ran)
         WN_HIP(ctx, hipMemsetAsync(kmax, 0, (size_t)(B + 16) * sizeof(unsigned), st));
-        hipLaunchKernelGGL(kr_max, dim3(G, B), dim3(RK_PT), 0, st, Y, n, kmax);
+        // (kp: the producer's workgroups left their maxima in slots; kr_hist takes the maximum over them and writes kmax)
+        if (!kp) hipLaunchKernelGGL(kr_max, dim3(G, B), dim3(RK_PT), 0, st, Y, n, kmax);
     }
+    const unsigned* kparts = (kp && !kmax_ready) ? kp->parts : nullptr;
+    const int kstride = kp ? kp->stride : 0, kcount = kp ? kp->count : 0;
     if (kmax_ready && hist_need) {
         // the few examples the producer could not do: one workgroup each, plain stores
-        hipLaunchKernelGGL(kr_hist, dim3(1, B), dim3(RK_PT), (size_t)NF * 4, st, Y, n, kmax, hist, NF, lgBPO, hist_need);
+        hipLaunchKernelGGL(kr_hist, dim3(1, B), dim3(RK_PT), (size_t)NF * 4, st, Y, n, kmax, hist, NF, lgBPO, hist_need, (const unsigned*)nullptr, 0, 0);
     } else {
         if (G > 1) WN_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)B * NF * sizeof(unsigned), st));
-        hipLaunchKernelGGL(kr_hist, dim3(G, B), dim3(RK_PT), (size_t)NF * 4, st, Y, n, kmax, hist, NF, lgBPO, (const unsigned*)nullptr);
+        hipLaunchKernelGGL(kr_hist, dim3(G, B), dim3(RK_PT), (size_t)NF * 4, st, Y, n, kmax, hist, NF, lgBPO, (const unsigned*)nullptr, kparts, kstride, kcount);
     }
     hipLaunchKernelGGL(kr_scan, dim3(B), dim3(RK_BT), (size_t)NF * 4, st, hist, kmax, NF, lgBPO, n, btab, meta, flag);
     const int sub = ctx->rank_sub > 0 ? std::min(ctx->rank_sub, B) : B;
@@ -1223,7 +1290,8 @@ int gini_buckets(wn_context* ctx, const double* Y, double* D, int B, size_t n, d
 int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, double* keysA, double* keysB,
                unsigned* idxA, unsigned* idxB, unsigned* cnt, double* gpart, double* fg, double* S_e, void* sort_tmp,
                size_t sort_tmp_bytes, int* rank_slice = nullptr, bool counts_ready = false, unsigned* kmax = nullptr,
-               bool kmax_ready = false, const unsigned** pending = nullptr, const unsigned* hist_need = nullptr, RankPairs* rp = nullptr) {
+               bool kmax_ready = false, const unsigned** pending = nullptr, const unsigned* hist_need = nullptr, RankPairs* rp = nullptr,
+               const KmaxParts* kp = nullptr) {
     // rank_slice (with D null): receives the number of examples per slice when the ranks were left in keysB
     // (slice s at keysB + s * slice * n, as 32-bit ranks at home positions) for a consumer that computes
     // the errors itself, 0 when this path did not apply and only the sums were computed.
@@ -1233,7 +1301,7 @@ int gini_large(wn_context* ctx, const double* Y, double* D, int B, size_t n, dou
     while (((size_t)1 << lgn) < n) lgn++;
     if (ctx->bucket_rank && !ctx->exact_sort && kmax) {
         bool ok = false;
-        const int rc = gini_buckets(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, fg, S_e, kmax, kmax_ready, &ok, pending, hist_need, rp);
+        const int rc = gini_buckets(ctx, Y, D, B, n, keysA, keysB, idxA, idxB, fg, S_e, kmax, kmax_ready, &ok, pending, hist_need, rp, kp);
         if (!ok && rp) rp->used = false;
         if (rc) return rc;
         if (ok) {
@@ -1404,6 +1472,7 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
         const int rowGroups = std::min(R / line_tile_rows(Mrow), LN_GX);
         int rowParts = 4 * rowGroups;
         unsigned* kmaxRows = fusedHist ? pl.idxA : nullptr;
+        KmaxParts kmaxParts{nullptr, 0, 0};
         unsigned* histNeed = fusedHist ? pl.kmax + (size_t)Bc + 16 : nullptr;
         size_t xs = n;
         int ncols = C, nrows = R;
@@ -1443,8 +1512,13 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
             if (kmaxArg) WN_HIP(ctx, hipMemsetAsync(kmaxArg, 0, (size_t)(Bc + 16) * sizeof(unsigned), st));   // and the ranking's flag behind them
             void* args[] = {(void*)&y1c, (void*)&YD, (void*)&pcolArg, (void*)&xs, (void*)&ncols, (void*)&dfilt, (void*)&counts, (void*)&kmaxArg};
             WN_HIP(ctx, hipLaunchKernel(line_kernel(NP, LN_FWD_COLS, Mcol), dim3((std::min(C, LN_GX) + 3) / 4, Bc), dim3(256), args, 0, st));
-        } else if ((rc = fwd_pass_big<NP>(ctx, Y1, Pcol, YD, Bc, n, cg))) {
-            return rc;
+        } else {
+            // long contiguous lines: the forward kernels leave the largest exponent words for the bucket ranking (in its
+            // index array, which is idle until the coefficients are partitioned; fewer than n / 128 slots per example)
+            unsigned* kparts = (!forward_only && buckets) ? pl.idxA : nullptr;
+            kmaxParts.parts = kparts;
+            kmaxParts.stride = (int)(n / 128);
+            if ((rc = fwd_pass_big<NP>(ctx, Y1, Pcol, YD, Bc, n, cg, kparts, kmaxParts.stride, &kmaxParts.count))) return rc;
         }
         if (forward_only) return WN_OK;
         double* S_e = S ? S + e0 : pl.S_e;
@@ -1460,7 +1534,7 @@ int train_impl(wn_context* ctx, const double* X, int B, int lgR, int lgC, double
             return rc;
         if (!rank_slice &&
             (rc = gini_large(ctx, YD, YD, Bc, n, pl.A, pl.Bb, pl.idxA, pl.idxB, pl.cnt, pl.gpart, pl.fg, S_e, pl.sort_tmp, pl.sort_tmp_bytes,
-                             nullptr, false, try_buckets ? pl.kmax : nullptr, false, pending)))
+                             nullptr, false, try_buckets ? pl.kmax : nullptr, false, pending, nullptr, nullptr, kmaxParts.count ? &kmaxParts : nullptr)))
             return rc;
         // the one-wave-per-line kernels write GXMAX slots per example
         const int pgx = (rowLines || colLines) ? GXMAX : pl.pgx;

@@ -129,14 +129,33 @@ __global__ __launch_bounds__(RK_PT) void kr_max(const double* __restrict__ Y, si
 // hist[e][f] (+)= number of non-zero coefficients of example e in bin f; grid (G, B), NF * 4 bytes of LDS.
 // G == 1: plain stores of every bin; else hist must be zero beforehand and the workgroups add.
 // only (may be null): the examples to do (only[e] != 0); the others have their histogram already.
-__global__ __launch_bounds__(RK_PT) void kr_hist(const double* __restrict__ Y, size_t n, const unsigned* __restrict__ kmax,
-                                                 unsigned* hist, int NF, int lgBPO, const unsigned* __restrict__ only) {
+// kparts (may be null): kmax[e] is not there yet -- it is the largest of the kcount words at kparts + e * kstride that
+// the producer's workgroups left; every workgroup works it out for itself and the first of an example writes kmax[e].
+__global__ __launch_bounds__(RK_PT) void kr_hist(const double* __restrict__ Y, size_t n, unsigned* __restrict__ kmax,
+                                                 unsigned* hist, int NF, int lgBPO, const unsigned* __restrict__ only,
+                                                 const unsigned* __restrict__ kparts, int kstride, int kcount) {
     extern __shared__ unsigned rk_h[];
+    __shared__ unsigned wmax[RK_PT / 64];
     const int e = blockIdx.y;
     if (only && !only[e]) return;
     for (int f = threadIdx.x; f < NF; f += RK_PT) rk_h[f] = 0;
+    unsigned km;
+    if (kparts) {
+        unsigned m = 0;
+        for (int i = threadIdx.x; i < kcount; i += RK_PT) m = max(m, kparts[(size_t)e * kstride + i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        km = wmax[0];
+#pragma unroll
+        for (int w = 1; w < RK_PT / 64; w++) km = max(km, wmax[w]);
+        if (blockIdx.x == 0 && threadIdx.x == 0) kmax[e] = km;
+    } else {
+        km = kmax[e];
+    }
     __syncthreads();
-    const unsigned Lmax = kmax[e] >> (20 - lgBPO);
+    const unsigned Lmax = km >> (20 - lgBPO);
     const size_t per = n / gridDim.x;
     const double* src = Y + (size_t)e * n + (size_t)blockIdx.x * per;
     for (size_t i0 = 0; i0 < per; i0 += 8 * RK_PT) {
