@@ -386,20 +386,32 @@ __global__ __launch_bounds__(LT) void kb_fwd_levels_lds(const double* __restrict
 // grid (workgroups per example <= pgx, examples); a workgroup walks over tiles of LT errors.  The operands of the
 // next tile are fetched into registers while the current one is worked on from LDS, so that a step does not
 // wait for a round trip to memory.
-template <int NP, bool PROP>
+// EPT: consecutive errors per thread.  The windows of neighbouring errors overlap in all but two activations, and
+// the errors their propagation reads in all but one: at two per thread a tile of 2 LT errors takes half the LDS reads
+// per error (and half the barriers).
+#ifndef WN_BWD_LDS_EPT
+#define WN_BWD_LDS_EPT 2
+#endif
+constexpr int BWD_LDS_EPT = WN_BWD_LDS_EPT;
+template <int NP, bool PROP, int EPT>
 __global__ __launch_bounds__(LT) void kb_bwd_level_lds(const double* __restrict__ lp, const double* __restrict__ hp,
                                                        const double* __restrict__ act, double* __restrict__ out, size_t xs, Geom g,
                                                        int lgLen, const FilterDev* filt, double* partial, int pgx) {
+    static_assert(EPT == 1 || EPT % 2 == 0, "one error per thread, or an even number (16-byte LDS reads)");
     constexpr int S = NP / 2;
     constexpr int JE = S & 1, JO = (S + 1) & 1;
     constexpr int CE = (JE - S) / 2, CO = (1 + JO - S) / 2;
     constexpr int CMIN = CE < CO ? CE : CO;
-    constexpr int EW = PROP ? LT + NP / 2 + 1 : LT;      // errors a tile reads: with PROP those its propagation needs, from r0 + CMIN on
+    constexpr int TE = EPT * LT;                         // errors per tile
+    constexpr int EW = PROP ? TE + NP / 2 + 1 : TE;      // errors a tile reads: with PROP those its propagation needs, from r0 + CMIN on
     constexpr int E0 = PROP ? -CMIN : 0;                 // position of error r0 among them
-    constexpr int AW = 2 * LT + NP;                      // activations a tile reads
+    constexpr int AW = 2 * TE + NP;                      // activations a tile reads
     constexpr int NA = (AW + LT - 1) / LT, NE = (EW + LT - 1) / LT;
-    __shared__ __attribute__((aligned(16))) double tile[AW];
-    __shared__ double tl[EW], th[EW];
+    constexpr int WN = NP + 2 * (EPT - 1);               // activations under a thread's windows
+    constexpr int VN = EPT + NP / 2;                     // errors under a thread's propagation
+    __shared__ __attribute__((aligned(16))) double tile[AW + 2];
+    __shared__ __attribute__((aligned(16))) double tl[EW + 3];
+    __shared__ __attribute__((aligned(16))) double th[EW + 3];
     __shared__ double red[(LT / 64) * 2 * NP];
     double a[NP], b[NP];
     load_taps<NP, taps_from_a(NP)>(filt, a, b);
@@ -426,9 +438,9 @@ __global__ __launch_bounds__(LT) void kb_bwd_level_lds(const double* __restrict_
             fh[q] = on ? hp[off + ((r0 - E0 + t) & rmask)] : 0.0;
         }
     };
-    int w0 = blockIdx.x * LT;
+    int w0 = blockIdx.x * TE;
     if (w0 < W) fetch(w0);
-    for (; w0 < W; w0 += gridDim.x * LT) {
+    for (; w0 < W; w0 += gridDim.x * TE) {
         const int line = w0 >> lgLen, r0 = w0 & rmask;
         const size_t off = (size_t)blockIdx.y * xs + (size_t)line * g.ls;
         rk::lds_barrier();       // the previous tile has been read (a barrier for LDS only: the store of its results may still be on its way)
@@ -443,26 +455,52 @@ __global__ __launch_bounds__(LT) void kb_bwd_level_lds(const double* __restrict_
             if (t < EW) { tl[t] = fl[q]; th[t] = fh[q]; }
         }
         rk::lds_barrier();
-        const int wnext = w0 + gridDim.x * LT;
+        const int wnext = w0 + gridDim.x * TE;
         if (wnext < W) fetch(wnext);
-        const double dl = tl[E0 + tid], dh = th[E0 + tid];
-        double win[NP];
-        read_window<NP>(tile, win);
+        // the activations under the windows of errors EPT tid .. EPT tid + EPT - 1: win[t] = tile[2 EPT tid + t]
+        double win[WN];
+        {
+            const double2* p = reinterpret_cast<const double2*>(tile + 2 * EPT * tid);
 #pragma unroll
-        for (int u = 0; u < NP; u++) {
-            gL[u] = __builtin_fma(dl, win[NP - 1 - u], gL[u]);
-            gH[u] = __builtin_fma(dh, win[NP - 1 - u], gH[u]);
+            for (int u = 0; u < WN / 2; u++) { const double2 t = p[u]; win[2 * u] = t.x; win[2 * u + 1] = t.y; }
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const double dl = tl[E0 + EPT * tid + k], dh = th[E0 + EPT * tid + k];
+#pragma unroll
+            for (int u = 0; u < NP; u++) {
+                gL[u] = __builtin_fma(dl, win[2 * k + NP - 1 - u], gL[u]);
+                gH[u] = __builtin_fma(dh, win[2 * k + NP - 1 - u], gH[u]);
+            }
         }
         if constexpr (PROP) {
-            double se = 0, so = 0;
+            // vl[t] = tl[EPT tid + t]: the errors from r0 + EPT tid + CMIN on
+            double vl[VN], vh[VN];
+            if constexpr (EPT == 1) {
 #pragma unroll
-            for (int i = 0; i < NP / 2; i++) {
-                se = __builtin_fma(a[JE + 2 * i], tl[tid + i + CE - CMIN], se);
-                se = __builtin_fma(b[JE + 2 * i], th[tid + i + CE - CMIN], se);
-                so = __builtin_fma(a[JO + 2 * i], tl[tid + i + CO - CMIN], so);
-                so = __builtin_fma(b[JO + 2 * i], th[tid + i + CO - CMIN], so);
+                for (int t = 0; t < VN; t++) { vl[t] = tl[tid + t]; vh[t] = th[tid + t]; }
+            } else {
+                const double2* pl2 = reinterpret_cast<const double2*>(tl + EPT * tid);
+                const double2* ph2 = reinterpret_cast<const double2*>(th + EPT * tid);
+#pragma unroll
+                for (int t = 0; t < VN / 2; t++) {
+                    const double2 x = pl2[t], y = ph2[t];
+                    vl[2 * t] = x.x; vl[2 * t + 1] = x.y;
+                    vh[2 * t] = y.x; vh[2 * t + 1] = y.y;
+                }
             }
-            *reinterpret_cast<double2*>(out + off + 2 * (r0 + tid)) = make_double2(se, so);
+#pragma unroll
+            for (int k = 0; k < EPT; k++) {
+                double se = 0, so = 0;
+#pragma unroll
+                for (int i = 0; i < NP / 2; i++) {
+                    se = __builtin_fma(a[JE + 2 * i], vl[k + i + CE - CMIN], se);
+                    se = __builtin_fma(b[JE + 2 * i], vh[k + i + CE - CMIN], se);
+                    so = __builtin_fma(a[JO + 2 * i], vl[k + i + CO - CMIN], so);
+                    so = __builtin_fma(b[JO + 2 * i], vh[k + i + CO - CMIN], so);
+                }
+                *reinterpret_cast<double2*>(out + off + 2 * (r0 + EPT * tid + k)) = make_double2(se, so);
+            }
         }
     }
     const double s = block_window_sums<NP, LT>(gL, gH, red, tid);
@@ -1054,14 +1092,18 @@ int bwd_pass_big(wn_context* ctx, const double* coef, const double* in, const do
         const bool propagate = (i != g.lgLen - 1 || lastPropagate);
         if (staged && partial && NP >= LDS_LEVEL_TAPS && g.es == 1 && !g.lanesOnLines && (1 << i) >= LT) {
             const double* act = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i);
-            const dim3 grid((unsigned)std::min<size_t>(((size_t)1 << (g.lgNL + i)) / LT, pgx), B);
+            const bool wide = BWD_LDS_EPT > 1 && (1 << i) >= BWD_LDS_EPT * LT;   // (a line's errors fill the wider tile)
+            const int te = wide ? BWD_LDS_EPT * LT : LT;
+            const dim3 grid((unsigned)std::min<size_t>(((size_t)1 << (g.lgNL + i)) / te, pgx), B);
+            double* none = nullptr;
             if (propagate) {
-                hipLaunchKernelGGL((kb_bwd_level_lds<NP, true>), grid, dim3(LT), 0, st, lp, hp, act, dst, n, g, i, ctx->dfilt, partial, pgx);
+                if (wide) hipLaunchKernelGGL((kb_bwd_level_lds<NP, true, BWD_LDS_EPT>), grid, dim3(LT), 0, st, lp, hp, act, dst, n, g, i, ctx->dfilt, partial, pgx);
+                else hipLaunchKernelGGL((kb_bwd_level_lds<NP, true, 1>), grid, dim3(LT), 0, st, lp, hp, act, dst, n, g, i, ctx->dfilt, partial, pgx);
                 lp = dst;
                 dst = (dst == pingA) ? pingB : pingA;
             } else {
-                hipLaunchKernelGGL((kb_bwd_level_lds<NP, false>), grid, dim3(LT), 0, st, lp, hp, act, (double*)nullptr, n, g, i, ctx->dfilt,
-                                   partial, pgx);
+                if (wide) hipLaunchKernelGGL((kb_bwd_level_lds<NP, false, BWD_LDS_EPT>), grid, dim3(LT), 0, st, lp, hp, act, none, n, g, i, ctx->dfilt, partial, pgx);
+                else hipLaunchKernelGGL((kb_bwd_level_lds<NP, false, 1>), grid, dim3(LT), 0, st, lp, hp, act, none, n, g, i, ctx->dfilt, partial, pgx);
             }
             continue;
         }
