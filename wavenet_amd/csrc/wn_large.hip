@@ -393,6 +393,10 @@ __global__ __launch_bounds__(LT) void kb_fwd_levels_lds(const double* __restrict
 #define WN_BWD_LDS_EPT 2
 #endif
 constexpr int BWD_LDS_EPT = WN_BWD_LDS_EPT;
+#ifndef WN_BWD_LDS_FILL
+#define WN_BWD_LDS_FILL 2
+#endif
+constexpr int BWD_LDS_FILL = WN_BWD_LDS_FILL;   // workgroups per CU the grid of kb_bwd_level_lds is sized for
 template <int NP, bool PROP, int EPT>
 __global__ __launch_bounds__(LT) void kb_bwd_level_lds(const double* __restrict__ lp, const double* __restrict__ hp,
                                                        const double* __restrict__ act, double* __restrict__ out, size_t xs, Geom g,
@@ -1094,7 +1098,10 @@ int bwd_pass_big(wn_context* ctx, const double* coef, const double* in, const do
             const double* act = (i == g.lgLen - 1) ? in : P + (size_t)(2 << i);
             const bool wide = BWD_LDS_EPT > 1 && (1 << i) >= BWD_LDS_EPT * LT;   // (a line's errors fill the wider tile)
             const int te = wide ? BWD_LDS_EPT * LT : LT;
-            const dim3 grid((unsigned)std::min<size_t>(((size_t)1 << (g.lgNL + i)) / te, pgx), B);
+            // workgroups per example: the kernel runs two to a CU (registers), and every one of them ends with the
+            // reduction of its window sums -- no more of them than fill the chip
+            const int fill = std::max(1, (BWD_LDS_FILL * ctx->numCU + B - 1) / B);
+            const dim3 grid((unsigned)std::min<size_t>(std::min<size_t>(((size_t)1 << (g.lgNL + i)) / te, pgx), fill), B);
             double* none = nullptr;
             if (propagate) {
                 if (wide) hipLaunchKernelGGL((kb_bwd_level_lds<NP, true, BWD_LDS_EPT>), grid, dim3(LT), 0, st, lp, hp, act, dst, n, g, i, ctx->dfilt, partial, pgx);
