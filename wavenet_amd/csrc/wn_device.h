@@ -428,6 +428,40 @@ __device__ __forceinline__ double xlane(double v, int lane) {
     }
 }
 
+// ---- the gradient's sums over the wave ------------------------------------------------------------------
+// c[k], k < NP (a power of two up to 32), summed over the 64 lanes; lane l returns the total of c[l mod NP].  A
+// butterfly that halves the set as it goes: on lane bit t a lane keeps the half of its values whose index has that
+// bit equal to its own and hands the other half to its partner, so NP - 1 exchanges settle the NP sums over groups
+// of NP lanes and one more per remaining lane bit completes them -- against six exchanges per value for a plain
+// butterfly of every value.  A fixed order of additions: the same bits from run to run.
+template <int NP, int CNT>
+__device__ __forceinline__ void wave_scatter_step(double (&c)[NP], int lane) {
+    if constexpr (CNT > 1) {
+        constexpr int H = CNT / 2;
+        const bool up = (lane & H) != 0;
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            const double keep = up ? c[i + H] : c[i];
+            const double send = up ? c[i] : c[i + H];
+            c[i] = keep + xlane<H>(send, lane);
+        }
+        wave_scatter_step<NP, H>(c, lane);
+    }
+}
+template <int NP>
+__device__ __forceinline__ double wave_scatter_sums(double (&c)[NP], int lane) {
+    static_assert(NP >= 1 && NP <= 32 && (NP & (NP - 1)) == 0, "a power of two up to 32");
+    wave_scatter_step<NP, NP>(c, lane);
+    double s = c[0];
+    if constexpr (NP <= 1) s += xlane<1>(s, lane);
+    if constexpr (NP <= 2) s += xlane<2>(s, lane);
+    if constexpr (NP <= 4) s += xlane<4>(s, lane);
+    if constexpr (NP <= 8) s += xlane<8>(s, lane);
+    if constexpr (NP <= 16) s += xlane<16>(s, lane);
+    s += xlane<32>(s, lane);
+    return s;
+}
+
 // Half-cleaners on index bits B..0 (compare e with e ^ 2^b, minimum to the lower index).
 template <int Q, int B>
 __device__ __forceinline__ void wave_clean(double (&v)[1 << Q], int lane) {

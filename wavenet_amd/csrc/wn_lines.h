@@ -771,13 +771,12 @@ __global__ __launch_bounds__(64, 2) void k_train_line(FusedArgs A) {
         for (int u = 0; u < NP; u++) { gL[u] = 0; gH[u] = 0; }
         ln_backward<NP, M, false>(p, dy, dtop, a, b, gL, gH, lane);
         // tap k' collects gL[k'] and sH[k'] gH[NP-1-k'], summed over the 64 lanes
-        double mine = 0;
+        double mine;
+        {
+            double c[NP];
 #pragma unroll
-        for (int kp = 0; kp < NP; kp++) {
-            double c = filt->vL[kp] * gL[kp] + (sg * filt->sH[kp]) * gH[NP - 1 - kp];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-            if (lane == kp) mine = c;
+            for (int kp = 0; kp < NP; kp++) c[kp] = filt->vL[kp] * gL[kp] + (sg * filt->sH[kp]) * gH[NP - 1 - kp];
+            mine = wave_scatter_sums<NP>(c, lane);      // the total of tap lane mod NP
         }
         const int k = lane - dpad;
         if (lane < NP && k >= 0 && k < N) {

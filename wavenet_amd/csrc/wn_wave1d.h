@@ -765,13 +765,23 @@ __global__ __launch_bounds__(256, W1D_WAVES) void k_train1d1024(FusedArgs A) {
         w1d_bwd_block<NP, 8, false>(d8, h8, xb, unused, a, b, gL, gH, lane);
 
         // tap k' collects gL[k'] and sH[k'] gH[NP-1-k'], summed over the 64 lanes
-        double mine = 0;
+        double mine;
+        {
+            double c[NP];
 #pragma unroll
-        for (int kp = 0; kp < NP; kp++) {
-            double c = filt->vL[kp] * gL[kp] + (sg * filt->sH[kp]) * gH[NP - 1 - kp];
+            for (int kp = 0; kp < NP; kp++) c[kp] = filt->vL[kp] * gL[kp] + (sg * filt->sH[kp]) * gH[NP - 1 - kp];
+#ifndef W1D_PLAIN_BUTTERFLY
+            mine = wave_scatter_sums<NP>(c, lane);       // the total of tap lane mod NP
+#else
+            mine = 0;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-            if (lane == kp) mine = c;
+            for (int kp = 0; kp < NP; kp++) {
+                double t = c[kp];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+                if (lane == kp) mine = t;
+            }
+#endif
         }
         const int k = lane - dpad;
         if (lane < NP && k >= 0 && k < N) {

@@ -607,13 +607,12 @@ __global__ __launch_bounds__(256, 1) void k_backprop64(FusedArgs A) {
             for (int c = 0; c < 64; c++) trow[c] = p[c];
         }
         w64_bwd_levels<NP, 0, W64_TOP_NONE, true>(v, w, trow, a, b, gL, gH);
-        double mine = 0;
+        double mine;
+        {
+            double c[NP];
 #pragma unroll
-        for (int kp = 0; kp < NP; kp++) {
-            double c = filt->vL[kp] * gL[kp] + filt->sH[kp] * gH[NP - 1 - kp];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-            if (lane == kp) mine = c;
+            for (int kp = 0; kp < NP; kp++) c[kp] = filt->vL[kp] * gL[kp] + filt->sH[kp] * gH[NP - 1 - kp];
+            mine = wave_scatter_sums<NP>(c, lane);      // the total of tap lane mod NP
         }
         const int k = lane - dpad;
         if (lane < NP && k >= 0 && k < N) A.grad[(size_t)e * N + k] = mine;
@@ -717,13 +716,23 @@ __global__ __launch_bounds__(256, 1) void k_train64(FusedArgs A) {
         w64_bwd_levels<NP, 0, W64_TOP_NONE, true>(v, w, trow, a, b, gL, gH);   // rows
 
         // tap k' collects gL[k'] and sH[k'] gH[NP-1-k'], summed over the 64 lanes
-        double mine = 0;
+        double mine;
+        {
+            double c[NP];
 #pragma unroll
-        for (int kp = 0; kp < NP; kp++) {
-            double c = filt->vL[kp] * gL[kp] + (sg * filt->sH[kp]) * gH[NP - 1 - kp];
+            for (int kp = 0; kp < NP; kp++) c[kp] = filt->vL[kp] * gL[kp] + (sg * filt->sH[kp]) * gH[NP - 1 - kp];
+#ifndef W64_PLAIN_BUTTERFLY
+            mine = wave_scatter_sums<NP>(c, lane);      // the total of tap lane mod NP
+#else
+            mine = 0;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-            if (lane == kp) mine = c;
+            for (int kp = 0; kp < NP; kp++) {
+                double t = c[kp];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+                if (lane == kp) mine = t;
+            }
+#endif
         }
         const int k = lane - dpad;
         if (lane < NP && k >= 0 && k < N) {
