@@ -64,6 +64,9 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+template <int M>
+__device__ __forceinline__ double xlane(double v, int lane);   // v of lane (lane ^ M), defined with the sort below
+
 // Sums over the wave's lanes of M values per lane at once (M a power of two, at most 64): returns, in lane l, the
 // sum over all lanes of v[l % M].  Butterfly steps at distances of M and more add all M values; below that a
 // lane keeps the half of its values that its own lane bit selects and hands the other half to its partner, so
@@ -73,14 +76,14 @@ template <int M, int OFF>
 __device__ __forceinline__ void wave_sum_scatter_step(double (&v)[M], int lane) {
     if constexpr (OFF >= M) {
 #pragma unroll
-        for (int i = 0; i < M; i++) v[i] += __shfl_xor(v[i], OFF, 64);
+        for (int i = 0; i < M; i++) v[i] += xlane<OFF>(v[i], lane);
     } else {
         const bool up = (lane & OFF) != 0;
 #pragma unroll
         for (int i = 0; i < OFF; i++) {
             const double keep = up ? v[i + OFF] : v[i];
             const double send = up ? v[i] : v[i + OFF];
-            v[i] = keep + __shfl_xor(send, OFF, 64);
+            v[i] = keep + xlane<OFF>(send, lane);
         }
     }
     if constexpr (OFF > 1) wave_sum_scatter_step<M, OFF / 2>(v, lane);
@@ -426,6 +429,18 @@ __device__ __forceinline__ double xlane(double v, int lane) {
         hi = __builtin_amdgcn_ds_bpermute(addr, hi);
         return __hiloint2double(hi, lo);
     }
+}
+
+// v summed over the wave by the butterfly at distances 32, 16, ... 1, the same bits in every lane -- the additions of
+// a loop over __shfl_xor, with DPP moves instead of ds_bpermute for the distances below 16.
+__device__ __forceinline__ double wave_allsum(double v, int lane) {
+    v += xlane<32>(v, lane);
+    v += xlane<16>(v, lane);
+    v += xlane<8>(v, lane);
+    v += xlane<4>(v, lane);
+    v += xlane<2>(v, lane);
+    v += xlane<1>(v, lane);
+    return v;
 }
 
 // ---- the gradient's sums over the wave ------------------------------------------------------------------

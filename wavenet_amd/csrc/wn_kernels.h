@@ -80,15 +80,11 @@ __device__ __forceinline__ double reduce_gradient(const double (&gL)[NP], const 
     constexpr int NWV = T / 64;
     double cp[NP];
 #pragma unroll
-    for (int k = 0; k < NP; k++) {
-        cp[k] = filt->vL[k] * gL[k] + (sg * filt->sH[k]) * gH[NP - 1 - k];
-        cp[k] = wave_sum(cp[k]);
-    }
+    for (int k = 0; k < NP; k++) cp[k] = filt->vL[k] * gL[k] + (sg * filt->sH[k]) * gH[NP - 1 - k];
+    const int lane = tid & 63;
+    const double mine = wave_scatter_sums<NP>(cp, lane);     // the wave's total of tap lane mod NP
     __syncthreads();
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < NP; k++) red[(tid >> 6) * NP + k] = cp[k];
-    }
+    if (lane < NP) red[(tid >> 6) * NP + lane] = mine;
     __syncthreads();
     double s = 0;
     if (tid < NP) {

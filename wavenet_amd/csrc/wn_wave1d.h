@@ -552,11 +552,8 @@ __device__ __forceinline__ bool w1d_gini_fast(const double (&y)[16], double* buf
         f = __builtin_fma(coef, ay, f);
         sabs += ay;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        f += __shfl_xor(f, off, 64);
-        sabs += __shfl_xor(sabs, off, 64);
-    }
+    f = wave_allsum(f, lane);
+    sabs = wave_allsum(sabs, lane);
     const double g = (double)n * sabs;
     const double inv_g2 = 1.0 / (g * g);
     double d[16];
