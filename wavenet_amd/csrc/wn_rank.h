@@ -474,10 +474,10 @@ __global__ __launch_bounds__(RK_PT) void kr_count(const double* __restrict__ Y, 
 // Packed keys of the non-zero magnitudes into their buckets' ranges of keys (per example n entries, bucket b at
 // [bstart[b], bstart[b+1])), and the cursor snapshots snap[(e * steps + step) * nbmax_even + b].  Steps as in kr_part.
 // grid (G, B), RK_PT threads; dynamic LDS: btab, NF * 2 bytes.  precnt: kr_count's counts (G > 1), else null.
-// The coefficients pass through kr_part8 once, while the buckets' partially written lines of keys (one open line per
-// bucket and workgroup: 2.4 MB per XCD at 300 buckets) should stay in the L2 until they are full: the loads are marked
-// non-temporal so that they do not push those lines out (measured: 437 -> 397 us for 64 signals of 2^20 samples,
-// 2.05 -> 1.99 ms for 2048 images of 512x512; RK_PART_PLAIN_LOADS compiles ordinary loads).
+// The coefficients pass through kr_part8 once: the loads are marked non-temporal (measured: 437 -> 397 us for 64
+// signals of 2^20 samples, 2.05 -> 1.99 ms for 2048 images of 512x512; RK_PART_PLAIN_LOADS compiles ordinary loads).
+// The bytes the kernel writes to memory do not change with it (1.0 GB for 0.54 GB of keys at 300 buckets per
+// signal, whose runs per step are 7 keys long), so what it buys is not fewer evictions of half-written lines.
 __device__ __forceinline__ double2 part_load(const double2* p) {
 #ifndef RK_PART_PLAIN_LOADS
     const double* q = reinterpret_cast<const double*>(p);
