@@ -965,7 +965,7 @@ __global__ __launch_bounds__(RK_KT, RK_B2_WAVES) void kr_bucket(const unsigned l
 __global__ __launch_bounds__(RK_KT) void kr_delta_regions(const double* Yin, const unsigned long long* __restrict__ pairs,
                                                           const unsigned short* __restrict__ snap, const unsigned* __restrict__ meta_all,
                                                           size_t n, int ib, const double* __restrict__ fg, double* Dout, const unsigned* flag) {
-    extern __shared__ unsigned rk_home[];
+    extern __shared__ __attribute__((aligned(16))) unsigned rk_home[];
     __shared__ unsigned run0[RK_NBMAX];              // per bucket: where the region's run of pairs starts, and its length
     __shared__ unsigned short runn[RK_NBMAX];
     if (*flag) return;
@@ -1020,12 +1020,18 @@ __global__ __launch_bounds__(RK_KT) void kr_delta_regions(const double* Yin, con
     const size_t off = (size_t)e * n + ((size_t)r << ib);
     const double f = fg[2 * e], g = fg[2 * e + 1], dn = (double)n;
     const double inv_g2 = 1.0 / (g * g);
-    for (unsigned j = (unsigned)tid; j <= mask; j += RK_KT) {
-        const double y = Yin[off + j];
+    // two coefficients per thread and step (regions are whole multiples of 2 RK_KT positions: ib >= RK_IB_MIN)
+    static_assert((1 << RK_IB_MIN) % (2 * RK_KT) == 0, "whole steps of two positions per thread");
+    auto delta = [&](double y, unsigned rank) {
         const double sg = sign_ref(y);
-        const double coef = (y != 0.0) ? 2.0 * (double)rk_home[j] - dn - 1.0 : 0.0;
+        const double coef = (y != 0.0) ? 2.0 * (double)rank - dn - 1.0 : 0.0;
         const double df = coef * sg;
-        Dout[off + j] = -(df * g - f * (dn * sg)) * inv_g2;
+        return -(df * g - f * (dn * sg)) * inv_g2;
+    };
+    for (unsigned j = 2u * (unsigned)tid; j <= mask; j += 2 * RK_KT) {
+        const double2 y = *reinterpret_cast<const double2*>(Yin + off + j);
+        const uint2 rk2 = *reinterpret_cast<const uint2*>(rk_home + j);
+        *reinterpret_cast<double2*>(Dout + off + j) = make_double2(delta(y.x, rk2.x), delta(y.y, rk2.y));
     }
 }
 
